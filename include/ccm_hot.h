@@ -1,0 +1,231 @@
+/* ccm_hot.h -- C ABI of the MI355X hot path for CCM-SLAM
+ * (ORB extraction, Hamming matching, reprojection bundle adjustment).
+ *
+ * This is the drop-in boundary: plain pointers and sizes,
+ * caller-allocated HOST buffers unless a name says `_dev`, int return 0 = OK or a
+ * negative CCM_E_* code, nothing throws.  One ccm_ctx per calling thread: it
+ * owns a HIP stream, device workspaces and (optionally) an RCCL communicator,
+ * so concurrent callers never share device state.
+ *
+ * All file:line citations are relative to the reference tree
+ * (taiyaki-go/motioncheck_ccm_slam).  INTEGRATION.md shows the C++ shim a
+ * maintainer adds on the reference side to forward the original classes here.
+ */
+#ifndef CCM_HOT_H
+#define CCM_HOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCM_ABI_VERSION 1
+
+enum {
+    CCM_OK = 0,
+    CCM_E_ARG = -1,       /* bad argument (null pointer, size <= 0, unsupported parameter) */
+    CCM_E_DEVICE = -2,    /* HIP runtime error; ccm_last_error() has the text */
+    CCM_E_NOMEM = -3,     /* host or device allocation failed */
+    CCM_E_CAPACITY = -4,  /* caller buffer too small (max_per_image, topk ...) */
+    CCM_E_NUMERIC = -5,   /* reduced system not positive definite in every LM trial */
+    CCM_E_COMM = -6,      /* RCCL error */
+    CCM_E_STATE = -7      /* call order violated (e.g. debug fetch before extract) */
+};
+
+typedef struct ccm_ctx ccm_ctx;
+
+/* ------------------------------------------------------------------ context */
+int ccm_abi_version(void);
+/* device = HIP device ordinal.  flags: reserved, pass 0. */
+ccm_ctx* ccm_create(int device, int flags);
+void ccm_destroy(ccm_ctx*);
+const char* ccm_last_error(const ccm_ctx*);
+/* Blocks until everything queued on the context's stream has finished. */
+int ccm_sync(ccm_ctx*);
+/* The hipStream_t the context launches on (for callers that time with HIP events). */
+void* ccm_stream(ccm_ctx*);
+
+/* ---------------------------------------------------------------- extractor
+ * Replaces ORBextractor::ORBextractor (cslam/src/ORBextractor.cpp:579-639) and
+ * ORBextractor::operator() (:1216-1278) with its callees ComputePyramid
+ * (:1280-1304), ComputeKeyPointsOctTree (:933-1024), DistributeOctTree
+ * (:707-931), IC_Angle (:68-95), GaussianBlur 7x7 sigma 2 (:1259) and
+ * computeOrbDescriptor (:100-316).                                           */
+typedef struct {
+    int   nfeatures;     /* ORBextractor.nFeatures   (cslam/conf/config.yaml:38-51) */
+    float scale_factor;  /* ORBextractor.scaleFactor */
+    int   nlevels;       /* ORBextractor.nLevels, 1..CCM_MAX_LEVELS */
+    int   ini_th_fast;   /* ORBextractor.iniThFAST */
+    int   min_th_fast;   /* ORBextractor.minThFAST */
+} ccm_orb_params;
+
+#define CCM_MAX_LEVELS 16
+
+/* Layout-identical to cv::KeyPoint (pt.x, pt.y, size, angle, response, octave,
+ * class_id): a std::vector<cv::KeyPoint>'s storage can be passed directly. */
+typedef struct {
+    float x, y;
+    float size;
+    float angle;     /* degrees [0,360) */
+    float response;  /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* always -1 */
+} ccm_keypoint;
+
+/* Constructor tables (getters GetScaleFactors / GetInverseScaleFactors /
+ * GetScaleSigmaSquares / GetInverseScaleSigmaSquares, include/cslam/ORBextractor.h:120-150).
+ * Each output may be NULL; arrays hold nlevels entries (umax: 16). Host only, no GPU. */
+int ccm_orb_tables(const ccm_orb_params*, float* scale, float* inv_scale, float* sigma2,
+                   float* inv_sigma2, int32_t* features_per_level, int32_t* umax);
+/* Pyramid level sizes for a w x h input (ORBextractor.cpp:1284-1285). Host only. */
+int ccm_orb_level_sizes(const ccm_orb_params*, int w, int h, int32_t* level_w, int32_t* level_h);
+
+/* Batched operator(): n_images 8-bit images of w x h (row stride `stride` bytes,
+ * image i starts at img + i*image_stride) -> per image up to max_per_image
+ * keypoints and 32-byte descriptors, rows in the reference's order (level-major,
+ * then DistributeOctTree list order).  kps: [n_images][max_per_image],
+ * desc: [n_images][max_per_image][32], counts: [n_images].
+ * n_images == 0 or w*h == 0 -> CCM_OK with nothing written (the reference
+ * returns silently on an empty image, ORBextractor.cpp:1219-1220).
+ * Returns CCM_E_CAPACITY if an image yields more than max_per_image keypoints
+ * (never happens with max_per_image >= nfeatures). */
+int ccm_orb_extract(ccm_ctx*, const ccm_orb_params*, const uint8_t* img, int w, int h, int stride,
+                    size_t image_stride, int n_images, ccm_keypoint* kps, uint8_t* desc,
+                    int32_t* counts, int max_per_image);
+
+/* Device-resident variant: img_dev is a device pointer; results stay on the
+ * device (fetch with ccm_orb_fetch) so that ccm_hamming_match_dev can consume
+ * the descriptors without a PCIe round trip.  The call is asynchronous on the
+ * context's stream.  */
+int ccm_orb_extract_dev(ccm_ctx*, const ccm_orb_params*, const uint8_t* img_dev, int w, int h,
+                        int stride, size_t image_stride, int n_images, int max_per_image);
+/* Copy the last ccm_orb_extract_dev results to host (any pointer may be NULL). */
+int ccm_orb_fetch(ccm_ctx*, ccm_keypoint* kps, uint8_t* desc, int32_t* counts);
+/* Device pointers of the last extract: desc_dev [n_images][max_per_image][32],
+ * counts_dev [n_images] (int32).  Valid until the next extract on this ctx. */
+int ccm_orb_result_dev(ccm_ctx*, const uint8_t** desc_dev, const int32_t** counts_dev,
+                       int* max_per_image);
+
+/* Test/debug taps of the last extract (host copies; synchronise internally):
+ * pyramid level pixels (mvImagePyramid, include/cslam/ORBextractor.h:152) ... */
+int ccm_orb_debug_level(ccm_ctx*, int image, int level, uint8_t* out, int out_stride);
+/* ... and the per-level FAST candidates before DistributeOctTree, in the order
+ * vToDistributeKeys is filled (ORBextractor.cpp:957-998): xy[2*i], xy[2*i+1]
+ * relative to minBorderX/Y as there, score[i].  Returns the count (>= 0) or an error. */
+int ccm_orb_debug_candidates(ccm_ctx*, int image, int level, int32_t* xy, int32_t* score, int max);
+
+/* ------------------------------------------------------------------ matcher
+ * ORBmatcher::DescriptorDistance (cslam/src/ORBmatcher.cpp:1653-1669): host helper. */
+int ccm_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+/* Brute-force best / second-best Hamming search, n_pairs independent problems
+ * (the inner loop of SearchByBoW, ORBmatcher.cpp:224-245, over one vocabulary
+ * node holding every feature).  q: [n_pairs][nq][32], t: [n_pairs][nt][32].
+ * Optional per-pair live counts nq_n/nt_n (NULL = all nq/nt rows live).
+ * Outputs per query: best_idx (lowest index wins ties, -1 if nt == 0),
+ * best_dist and second_dist (256 when absent), exactly the running
+ * (bestDist1,bestIdx,bestDist2) of the reference with strict `<`. */
+int ccm_hamming_match(ccm_ctx*, const uint8_t* q, int nq, const uint8_t* t, int nt, int n_pairs,
+                      const int32_t* nq_n, const int32_t* nt_n,
+                      int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* Same on device pointers (descriptor strides in rows), asynchronous. */
+int ccm_hamming_match_dev(ccm_ctx*, const uint8_t* q_dev, int nq, size_t q_pair_stride,
+                          const uint8_t* t_dev, int nt, size_t t_pair_stride, int n_pairs,
+                          const int32_t* nq_n_dev, const int32_t* nt_n_dev,
+                          int32_t* best_idx_dev, int32_t* best_dist_dev, int32_t* second_dist_dev);
+
+/* Acceptance test applied by the callers (ORBmatcher.cpp:247-249): host helper.
+ * strict = 0 -> best <= th (Frame variant), 1 -> best < th (KF-KF variant, :641). */
+int ccm_ratio_test(int best_dist, int second_dist, float nnratio, int th, int strict);
+
+/* ORBmatcher::SearchByBoW, both overloads (ORBmatcher.cpp:178-306, 565-698), for one pair.
+ * Side 1 = the keyframe whose features drive the outer loop, side 2 = the
+ * frame/keyframe searched.  node1/node2: vocabulary node id of every feature
+ * (the FeatureVector, as one id per feature; features with the same id are
+ * visited in ascending feature index, as DBoW2 fills them).  valid1: feature
+ * has a good MapPoint (pMP && !isBad).  valid2: NULL for the Frame overload
+ * (every frame feature is a candidate), else the KF-KF validity mask.
+ * angle1/angle2: keypoint angles (degrees) for the rotation histogram.
+ * Output match12[n1]: index into side 2 or -1 -- the KF-KF overload's
+ * vpMatches12; for the Frame overload the reference fills
+ * vpMapPointMatches[idx2] = MP(idx1), the shim inverts it.  Returns the number
+ * of matches (>= 0) or an error. */
+typedef struct {
+    float nnratio;        /* mfNNratio */
+    int   check_ori;      /* mbCheckOrientation */
+    int   th;             /* TH_LOW = 50 */
+    int   strict_th;      /* 0: best <= th (Frame overload), 1: best < th (KF-KF) */
+} ccm_bow_options;
+int ccm_match_bow(ccm_ctx*, const ccm_bow_options*,
+                  const uint8_t* desc1, const int32_t* node1, const uint8_t* valid1,
+                  const float* angle1, int n1,
+                  const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2,
+                  const float* angle2, int n2, int32_t* match12);
+
+/* ---------------------------------------------------------------- optimizer
+ * The 6-DoF pose / 3-DoF point reprojection BA that Optimizer::BundleAdjustmentClient
+ * (src/Optimizer.cpp:32-212), LocalBundleAdjustmentClient (:349-644) and
+ * MapFusionGBA (:646-865) hand to g2o: EdgeSE3ProjectXYZ residual/Jacobian
+ * (thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:103-147), Huber kernel,
+ * BlockSolver_6_3 Schur complement (core/block_solver.hpp:354-486) and the
+ * Levenberg loop (core/optimization_algorithm_levenberg.cpp:61-189).          */
+typedef struct {
+    int      n_poses;
+    double*  poses;        /* [n_poses][7]: unit quaternion (x,y,z,w) then t (x,y,z) = SE3Quat of Tcw; in/out */
+    const uint8_t* fixed;  /* [n_poses] 1 = setFixed(true) */
+    const double*  intr;   /* [n_poses][4] fx,fy,cx,cy */
+    int      n_points;
+    double*  points;       /* [n_points][3] world xyz; in/out */
+    int      n_edges;
+    const int32_t* edge_pose;   /* [n_edges] */
+    const int32_t* edge_point;  /* [n_edges] */
+    const double*  obs;         /* [n_edges][2] u,v */
+    const double*  info;        /* [n_edges] invSigma2 (information = info * I2) */
+} ccm_ba_problem;
+
+typedef struct {
+    int    iterations;     /* optimize(n) */
+    double huber_delta;    /* thHuber2D; <= 0 -> no robust kernel */
+    /* Local BA's second stage (Optimizer.cpp:546-568): after `iterations`, mark
+     * edges with chi2 > outlier_chi2 or non-positive depth as level 1, drop the
+     * kernels and run `iterations2` more.  iterations2 <= 0 -> single stage. */
+    int    iterations2;
+    double outlier_chi2;   /* 5.991 */
+    const volatile uint8_t* stop_flag; /* pbStopFlag, polled between LM iterations/trials; may be NULL */
+} ccm_ba_options;
+
+typedef struct {
+    int    iterations_done;   /* LM iterations run, both stages */
+    int    trials;            /* linear solves */
+    double chi2_initial;      /* activeRobustChi2 before the first iteration */
+    double chi2_final;        /* activeRobustChi2 at the last accepted state */
+    double lambda_final;
+    int    stopped;           /* 1 if stop_flag ended the solve */
+    /* per-stage wall seconds, mirroring G2OBatchStatistics (core/batch_stats.h) */
+    double t_linearize, t_schur, t_solve, t_update;
+    uint8_t* edge_outlier;    /* optional out [n_edges]: chi2 > outlier_chi2 || depth <= 0 at the end (:582) */
+} ccm_ba_result;
+
+int ccm_ba_solve(ccm_ctx*, ccm_ba_problem*, const ccm_ba_options*, ccm_ba_result*);
+
+/* Multi-GPU GBA: every rank calls ccm_ba_solve with the
+ * SAME poses and ITS OWN landmark partition (points + their edges); the reduced
+ * camera system is summed with one RCCL all-reduce per LM trial.  One rank
+ * makes an id, the host program distributes it (e.g. torch.distributed
+ * broadcast), every rank calls ccm_comm_init.  */
+#define CCM_COMM_ID_BYTES 128
+int ccm_comm_unique_id(uint8_t id[CCM_COMM_ID_BYTES]);
+int ccm_comm_init(ccm_ctx*, const uint8_t id[CCM_COMM_ID_BYTES], int n_ranks, int rank);
+int ccm_comm_destroy(ccm_ctx*);
+
+/* SE3Quat / Converter helpers (src/Converter.cc:40-56, 86-93): float32 4x4 row-major
+ * Tcw <-> quaternion+translation double[7]. Host only. */
+int ccm_pose_from_mat4f(const float* T16, double* pose7);
+int ccm_pose_to_mat4f(const double* pose7, float* T16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,544 @@
+#define _GNU_SOURCE
+/* ba_oracle.c -- CPU restatement (float64) of the 6-DoF pose / 3-DoF point
+ * reprojection bundle adjustment that Optimizer.cpp hands to g2o.
+ * TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * Follows, in the reference tree:
+ *   cslam/thirdparty/g2o/g2o/types/types_six_dof_expmap.{h,cpp}   (edge error + Jacobians)
+ *   cslam/thirdparty/g2o/g2o/types/se3quat.h, se3_ops.hpp          (exp map, composition)
+ *   cslam/thirdparty/g2o/g2o/core/base_binary_edge.hpp:55-120      (quadratic form)
+ *   cslam/thirdparty/g2o/g2o/core/robust_kernel_impl.cpp:78-91     (Huber)
+ *   cslam/thirdparty/g2o/g2o/core/block_solver.hpp:354-486,564-604 (Schur, lambda)
+ *   cslam/thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-189
+ *   cslam/thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-435
+ *   src/Optimizer.cpp:536-602 (local BA's two-stage schedule), src/Converter.cc:40-119
+ * Eigen (Quaterniond(R), 3x3 inverse, SimplicialLDLT) is not in the tree: its
+ * arithmetic is restated; the reduced system is solved by dense Cholesky, any
+ * exact SPD solve being equivalent up to rounding.  Edge
+ * summation order here is edge-array order; g2o's depends on pointer-ordered
+ * maps, so bitwise equality with g2o is impossible by construction and the
+ * contract is a tolerance (1e-5 on pose updates).  PARITY UNPINNED vs g2o.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- rotations */
+static void quat_to_R(const double* q, double* R)   /* q = x,y,z,w ; Eigen toRotationMatrix */
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+static void R_to_quat(const double* m, double* q)   /* Eigen Quaterniond(Matrix3d) */
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 3 + i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+}
+static void quat_normalize(double* q)                /* SE3Quat::normalizeRotation, se3quat.h:280-285 */
+{
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void quat_mul(const double* a, const double* b, double* o)
+{
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+static void mat3_mul(const double* A, const double* B, double* C)
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+        C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+
+/* T_out = exp(delta) * T_in : VertexSE3Expmap::oplusImpl (types_six_dof_expmap.h:73-76),
+ * SE3Quat::exp (se3quat.h:223-257), operator* (:104-110). delta = (omega, upsilon). */
+void orc_se3_exp_mul(const double* d, const double* Tin, double* Tout)
+{
+    const double om[3] = { d[0], d[1], d[2] }, up[3] = { d[3], d[4], d[5] };
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
+    double O2[9], R[9], V[9];
+    mat3_mul(O, O, O2);
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; i++) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
+        const double c = (theta - sin(theta)) / pow(theta, 3);
+        for (int i = 0; i < 9; i++) {
+            const double I = (i % 4 == 0 ? 1.0 : 0.0);
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    double qe[4], te[3];
+    R_to_quat(R, qe);
+    for (int i = 0; i < 3; i++) te[i] = V[i * 3] * up[0] + V[i * 3 + 1] * up[1] + V[i * 3 + 2] * up[2];
+    /* result = exp * Tin */
+    double Re[9], q[4];
+    quat_to_R(qe, Re);
+    quat_mul(qe, Tin, q);
+    double t[3];
+    for (int i = 0; i < 3; i++)
+        t[i] = te[i] + Re[i * 3] * Tin[4] + Re[i * 3 + 1] * Tin[5] + Re[i * 3 + 2] * Tin[6];
+    quat_normalize(q);
+    for (int i = 0; i < 4; i++) Tout[i] = q[i];
+    for (int i = 0; i < 3; i++) Tout[4 + i] = t[i];
+}
+
+/* Converter::toSE3Quat (src/Converter.cc:40-56): float 4x4 -> double R,t -> SE3Quat(R,t) */
+void orc_pose_from_mat4f(const float* T, double* pose)
+{
+    double R[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = (double)T[i * 4 + j];
+    R_to_quat(R, pose);
+    quat_normalize(pose);                                  /* SE3Quat ctor normalises */
+    for (int i = 0; i < 3; i++) pose[4 + i] = (double)T[i * 4 + 3];
+}
+/* Converter::toCvMat(SE3Quat) (src/Converter.cc:86-93) */
+void orc_pose_to_mat4f(const double* pose, float* T)
+{
+    double R[9];
+    quat_to_R(pose, R);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[i * 4 + j] = (float)R[i * 3 + j];
+        T[i * 4 + 3] = (float)pose[4 + i];
+    }
+    T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+}
+
+/* ---------------------------------------------------------------- one edge
+ * computeError (types_six_dof_expmap.h:90-101) + linearizeOplus (.cpp:103-139) */
+static void edge_eval(const double* R, const double* t, const double* K, const double* p,
+                      const double* obs, double* e, double* A, double* B, double* zout)
+{
+    const double x = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
+    const double y = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
+    const double z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    e[0] = obs[0] - (x / z * fx + cx);
+    e[1] = obs[1] - (y / z * fy + cy);
+    if (zout) *zout = z;
+    if (!A) return;
+    const double z2 = z * z;
+    const double tm[6] = { fx, 0, -x / z * fx, 0, fy, -y / z * fy };
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++)
+        A[i * 3 + j] = -1. / z * (tm[i * 3] * R[j] + tm[i * 3 + 1] * R[3 + j] + tm[i * 3 + 2] * R[6 + j]);
+    B[0] = x * y / z2 * fx;  B[1] = -(1 + (x * x / z2)) * fx;  B[2] = y / z * fx;
+    B[3] = -1. / z * fx;     B[4] = 0;                          B[5] = x / z2 * fx;
+    B[6] = (1 + y * y / z2) * fy;  B[7] = -x * y / z2 * fy;     B[8] = -x / z * fy;
+    B[9] = 0;                B[10] = -1. / z * fy;              B[11] = y / z2 * fy;
+}
+
+void orc_ba_edge(const double* pose7, const double* intr4, const double* pt3, const double* obs2,
+                 double* err2, double* A, double* B)
+{
+    double R[9];
+    quat_to_R(pose7, R);
+    edge_eval(R, pose7 + 4, intr4, pt3, obs2, err2, A, B, 0);
+}
+
+/* RobustKernelHuber::robustify, robust_kernel_impl.cpp:78-91 */
+static void huber(double e, double delta, double* rho0, double* rho1)
+{
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { *rho0 = e; *rho1 = 1.; }
+    else { const double s = sqrt(e); *rho0 = 2 * s * delta - dsqr; *rho1 = delta / s; }
+}
+
+/* ---------------------------------------------------------------- solver state */
+typedef struct {
+    const orc_ba_problem* pb;
+    int P, L, E;
+    int nfree; int* free_of;          /* pose -> free index or -1 */
+    double* R;                         /* [P][9] */
+    uint8_t* active;                   /* [E] level 0 */
+    double* err;                       /* [E][2] last computed (stale for inactive edges, like g2o) */
+    double huber_delta;                /* <= 0: none */
+    /* system */
+    double* Hpp; double* bp;           /* [nfree][36], [nfree][6] */
+    double* Hll; double* bl;           /* [L][9], [L][3] */
+    double* Hpl;                       /* [E][18] (6x3), zero for fixed / inactive */
+    double* Hs; double* bs;            /* dense 6nfree x 6nfree, 6nfree */
+    double* x;                         /* [6nfree + 3L] */
+    double* Dinv; double* coeff;
+    int* pt_first; int* pt_edges;      /* CSR landmark -> edges (sorted by pose) */
+} ba_t;
+
+static void refresh_R(ba_t* s)
+{
+    for (int i = 0; i < s->P; i++) quat_to_R(s->pb->poses + 7 * i, s->R + 9 * i);
+}
+
+/* computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:61-114) */
+static double compute_errors(ba_t* s)
+{
+    const orc_ba_problem* pb = s->pb;
+    refresh_R(s);
+    double chi = 0;
+    for (int e = 0; e < s->E; e++) {
+        if (!s->active[e]) continue;
+        const int pi = pb->edge_pose[e], li = pb->edge_point[e];
+        edge_eval(s->R + 9 * pi, pb->poses + 7 * pi + 4, pb->intr + 4 * pi, pb->points + 3 * li,
+                  pb->obs + 2 * e, s->err + 2 * e, 0, 0, 0);
+        const double c2 = pb->info[e] * (s->err[2 * e] * s->err[2 * e] + s->err[2 * e + 1] * s->err[2 * e + 1]);
+        if (s->huber_delta > 0) { double r0, r1; huber(c2, s->huber_delta, &r0, &r1); chi += r0; }
+        else chi += c2;
+    }
+    return chi;
+}
+
+/* BlockSolver::buildSystem (block_solver.hpp:502-560) */
+static void build_system(ba_t* s)
+{
+    const orc_ba_problem* pb = s->pb;
+    memset(s->Hpp, 0, sizeof(double) * 36 * (size_t)s->nfree);
+    memset(s->bp, 0, sizeof(double) * 6 * (size_t)s->nfree);
+    memset(s->Hll, 0, sizeof(double) * 9 * (size_t)s->L);
+    memset(s->bl, 0, sizeof(double) * 3 * (size_t)s->L);
+    memset(s->Hpl, 0, sizeof(double) * 18 * (size_t)s->E);
+    for (int e = 0; e < s->E; e++) {
+        if (!s->active[e]) continue;
+        const int pi = pb->edge_pose[e], li = pb->edge_point[e];
+        double er[2], A[6], B[12];
+        edge_eval(s->R + 9 * pi, pb->poses + 7 * pi + 4, pb->intr + 4 * pi, pb->points + 3 * li,
+                  pb->obs + 2 * e, er, A, B, 0);
+        const double om = pb->info[e];
+        double r1 = 1.;
+        if (s->huber_delta > 0) { double r0; huber(om * (er[0] * er[0] + er[1] * er[1]), s->huber_delta, &r0, &r1); }
+        const double w = r1 * om;
+        const double g0 = -om * er[0] * r1, g1 = -om * er[1] * r1;   /* omega_r * rho[1] */
+        double* Hl = s->Hll + 9 * (size_t)li; double* b_l = s->bl + 3 * (size_t)li;
+        for (int i = 0; i < 3; i++) {
+            b_l[i] += A[i] * g0 + A[3 + i] * g1;
+            for (int j = 0; j < 3; j++) Hl[i * 3 + j] += w * (A[i] * A[j] + A[3 + i] * A[3 + j]);
+        }
+        const int f = s->free_of[pi];
+        if (f >= 0) {
+            double* Hp = s->Hpp + 36 * (size_t)f; double* b_p = s->bp + 6 * (size_t)f;
+            double* Hx = s->Hpl + 18 * (size_t)e;
+            for (int i = 0; i < 6; i++) {
+                b_p[i] += B[i] * g0 + B[6 + i] * g1;
+                for (int j = 0; j < 6; j++) Hp[i * 6 + j] += w * (B[i] * B[j] + B[6 + i] * B[6 + j]);
+                for (int j = 0; j < 3; j++) Hx[i * 3 + j] = w * (B[i] * A[j] + B[6 + i] * A[3 + j]);
+            }
+        }
+    }
+}
+
+static int inv3(const double* m, double* o)      /* cofactor inverse, as Eigen does for 3x3 */
+{
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return isfinite(id);
+}
+
+/* dense Cholesky A = L L^T in the lower triangle, row-major n x n; returns 0 if not SPD */
+static int chol_factor(double* A, int n)
+{
+    for (int j = 0; j < n; j++) {
+        double* Aj = A + (size_t)j * n;
+        double d = Aj[j];
+        for (int k = 0; k < j; k++) d -= Aj[k] * Aj[k];
+        if (!(d > 0)) return 0;
+        d = sqrt(d);
+        Aj[j] = d;
+        const double id = 1.0 / d;
+        for (int i = j + 1; i < n; i++) {
+            double* Ai = A + (size_t)i * n;
+            double v = Ai[j];
+            for (int k = 0; k < j; k++) v -= Ai[k] * Aj[k];
+            Ai[j] = v * id;
+        }
+    }
+    return 1;
+}
+static void chol_solve(const double* A, int n, double* b)
+{
+    for (int i = 0; i < n; i++) {
+        double v = b[i];
+        const double* Ai = A + (size_t)i * n;
+        for (int k = 0; k < i; k++) v -= Ai[k] * b[k];
+        b[i] = v / Ai[i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double v = b[i];
+        for (int k = i + 1; k < n; k++) v -= A[(size_t)k * n + i] * b[k];
+        b[i] = v / A[(size_t)i * n + i];
+    }
+}
+
+/* Schur reduction of BlockSolver::solve (block_solver.hpp:370-439) with lambda added to every
+ * diagonal element (setLambda :564-589).  Fills Hs (full symmetric) and bs. */
+static void schur_reduce(ba_t* s, double lambda)
+{
+    const int n = 6 * s->nfree;
+    memset(s->Hs, 0, sizeof(double) * (size_t)n * n);
+    memset(s->coeff, 0, sizeof(double) * n);
+    for (int f = 0; f < s->nfree; f++)
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++)
+            s->Hs[(size_t)(6 * f + i) * n + 6 * f + j] = s->Hpp[36 * (size_t)f + i * 6 + j] + (i == j ? lambda : 0.0);
+    for (int l = 0; l < s->L; l++) {
+        double D[9], db[3];
+        memcpy(D, s->Hll + 9 * (size_t)l, sizeof D);
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        double* Di = s->Dinv + 9 * (size_t)l;
+        inv3(D, Di);
+        const double* b_l = s->bl + 3 * (size_t)l;
+        for (int i = 0; i < 3; i++) db[i] = Di[i * 3] * b_l[0] + Di[i * 3 + 1] * b_l[1] + Di[i * 3 + 2] * b_l[2];
+        for (int a = s->pt_first[l]; a < s->pt_first[l + 1]; a++) {
+            const int e1 = s->pt_edges[a];
+            const int f1 = s->free_of[s->pb->edge_pose[e1]];
+            if (f1 < 0 || !s->active[e1]) continue;
+            const double* Bi = s->Hpl + 18 * (size_t)e1;
+            double BD[18];
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++)
+                BD[i * 3 + j] = Bi[i * 3] * Di[j] + Bi[i * 3 + 1] * Di[3 + j] + Bi[i * 3 + 2] * Di[6 + j];
+            for (int i = 0; i < 6; i++)
+                s->coeff[6 * f1 + i] += Bi[i * 3] * db[0] + Bi[i * 3 + 1] * db[1] + Bi[i * 3 + 2] * db[2];
+            for (int b = a; b < s->pt_first[l + 1]; b++) {
+                const int e2 = s->pt_edges[b];
+                const int f2 = s->free_of[s->pb->edge_pose[e2]];
+                if (f2 < 0 || !s->active[e2]) continue;
+                const double* Bj = s->Hpl + 18 * (size_t)e2;
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+                    const double v = BD[i * 3] * Bj[j * 3] + BD[i * 3 + 1] * Bj[j * 3 + 1] + BD[i * 3 + 2] * Bj[j * 3 + 2];
+                    s->Hs[(size_t)(6 * f1 + i) * n + 6 * f2 + j] -= v;
+                    if (f1 != f2) s->Hs[(size_t)(6 * f2 + j) * n + 6 * f1 + i] -= v;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n; i++) s->bs[i] = s->bp[i] - s->coeff[i];
+}
+
+/* solve with the current lambda; x = [poses | landmarks]; returns 0 if the reduced system is not SPD */
+static int schur_solve(ba_t* s, double lambda)
+{
+    const int n = 6 * s->nfree;
+    schur_reduce(s, lambda);
+    if (n > 0) {
+        if (!chol_factor(s->Hs, n)) return 0;
+        memcpy(s->x, s->bs, sizeof(double) * n);
+        chol_solve(s->Hs, n, s->x);
+    }
+    /* landmarks: xl = Dinv (bl - Hpl^T xp)  (block_solver.hpp:461-481) */
+    for (int l = 0; l < s->L; l++) {
+        double c[3] = { s->bl[3 * l], s->bl[3 * l + 1], s->bl[3 * l + 2] };
+        for (int a = s->pt_first[l]; a < s->pt_first[l + 1]; a++) {
+            const int e = s->pt_edges[a];
+            const int f = s->free_of[s->pb->edge_pose[e]];
+            if (f < 0 || !s->active[e]) continue;
+            const double* Bi = s->Hpl + 18 * (size_t)e;
+            const double* xp = s->x + 6 * f;
+            for (int j = 0; j < 3; j++)
+                for (int i = 0; i < 6; i++) c[j] -= Bi[i * 3 + j] * xp[i];
+        }
+        const double* Di = s->Dinv + 9 * (size_t)l;
+        double* xl = s->x + n + 3 * l;
+        for (int i = 0; i < 3; i++) xl[i] = Di[i * 3] * c[0] + Di[i * 3 + 1] * c[1] + Di[i * 3 + 2] * c[2];
+    }
+    return 1;
+}
+
+static int cmp_edge_pose(const void* a, const void* b, void* ctx)
+{
+    const int32_t* ep = (const int32_t*)ctx;
+    const int x = *(const int*)a, y = *(const int*)b;
+    if (ep[x] != ep[y]) return ep[x] < ep[y] ? -1 : 1;
+    return x < y ? -1 : (x > y);
+}
+
+static ba_t* ba_new(orc_ba_problem* pb)
+{
+    ba_t* s = (ba_t*)calloc(1, sizeof(ba_t));
+    s->pb = pb; s->P = pb->n_poses; s->L = pb->n_points; s->E = pb->n_edges;
+    s->free_of = (int*)malloc(sizeof(int) * (s->P + 1));
+    s->nfree = 0;
+    for (int i = 0; i < s->P; i++) s->free_of[i] = (pb->fixed && pb->fixed[i]) ? -1 : s->nfree++;
+    const int n = 6 * s->nfree;
+    s->R = (double*)malloc(sizeof(double) * 9 * (size_t)(s->P + 1));
+    s->active = (uint8_t*)malloc(s->E + 1); memset(s->active, 1, s->E + 1);
+    s->err = (double*)calloc(2 * (size_t)s->E + 2, sizeof(double));
+    s->Hpp = (double*)malloc(sizeof(double) * 36 * (size_t)(s->nfree + 1));
+    s->bp = (double*)malloc(sizeof(double) * 6 * (size_t)(s->nfree + 1));
+    s->Hll = (double*)malloc(sizeof(double) * 9 * (size_t)(s->L + 1));
+    s->bl = (double*)malloc(sizeof(double) * 3 * (size_t)(s->L + 1));
+    s->Hpl = (double*)malloc(sizeof(double) * 18 * (size_t)(s->E + 1));
+    s->Hs = (double*)malloc(sizeof(double) * ((size_t)n * n + 1));
+    s->bs = (double*)malloc(sizeof(double) * (n + 1));
+    s->x = (double*)calloc((size_t)n + 3 * (size_t)s->L + 1, sizeof(double));
+    s->Dinv = (double*)malloc(sizeof(double) * 9 * (size_t)(s->L + 1));
+    s->coeff = (double*)malloc(sizeof(double) * (n + 1));
+    s->pt_first = (int*)calloc(s->L + 2, sizeof(int));
+    s->pt_edges = (int*)malloc(sizeof(int) * (s->E + 1));
+    for (int e = 0; e < s->E; e++) s->pt_first[pb->edge_point[e] + 1]++;
+    for (int l = 0; l < s->L; l++) s->pt_first[l + 1] += s->pt_first[l];
+    int* fill = (int*)malloc(sizeof(int) * (s->L + 1));
+    memcpy(fill, s->pt_first, sizeof(int) * (s->L + 1));
+    for (int e = 0; e < s->E; e++) s->pt_edges[fill[pb->edge_point[e]]++] = e;
+    for (int l = 0; l < s->L; l++)
+        qsort_r(s->pt_edges + s->pt_first[l], s->pt_first[l + 1] - s->pt_first[l], sizeof(int),
+                cmp_edge_pose, (void*)pb->edge_pose);
+    free(fill);
+    return s;
+}
+static void ba_free(ba_t* s)
+{
+    free(s->free_of); free(s->R); free(s->active); free(s->err); free(s->Hpp); free(s->bp);
+    free(s->Hll); free(s->bl); free(s->Hpl); free(s->Hs); free(s->bs); free(s->x); free(s->Dinv);
+    free(s->coeff); free(s->pt_first); free(s->pt_edges); free(s);
+}
+
+/* SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration */
+static int lm_optimize(ba_t* s, int iterations, orc_ba_result* res, double* lambda_io)
+{
+    orc_ba_problem* pb = (orc_ba_problem*)s->pb;
+    const int n = 6 * s->nfree, nx = n + 3 * s->L;
+    double lambda = 0, ni = 2;
+    int nBad = 0, done = 0;
+    double* save_pose = (double*)malloc(sizeof(double) * 7 * (size_t)(s->P + 1));
+    double* save_pt = (double*)malloc(sizeof(double) * 3 * (size_t)(s->L + 1));
+    for (int it = 0; it < iterations; it++) {
+        double currentChi = compute_errors(s);
+        const double iniChi = currentChi;
+        if (res && res->iterations_done == 0 && it == 0 && res->chi2_initial < 0) res->chi2_initial = currentChi;
+        build_system(s);
+        if (it == 0) {                                             /* computeLambdaInit :166-180 */
+            double md = 0;
+            for (int f = 0; f < s->nfree; f++) for (int j = 0; j < 6; j++) md = fmax(fabs(s->Hpp[36 * (size_t)f + 7 * j]), md);
+            for (int l = 0; l < s->L; l++) for (int j = 0; j < 3; j++) md = fmax(fabs(s->Hll[9 * (size_t)l + 4 * j]), md);
+            lambda = 1e-5 * md; ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            memcpy(save_pose, pb->poses, sizeof(double) * 7 * (size_t)s->P);      /* push */
+            memcpy(save_pt, pb->points, sizeof(double) * 3 * (size_t)s->L);
+            const int ok2 = schur_solve(s, lambda);
+            if (res) res->trials++;
+            double tempChi;
+            if (ok2) {
+                for (int p = 0; p < s->P; p++) {                                     /* update :422-435 */
+                    const int f = s->free_of[p];
+                    if (f < 0) continue;
+                    double o[7];
+                    orc_se3_exp_mul(s->x + 6 * f, pb->poses + 7 * p, o);
+                    memcpy(pb->poses + 7 * p, o, sizeof o);
+                }
+                for (int l = 0; l < s->L; l++) for (int j = 0; j < 3; j++) pb->points[3 * l + j] += s->x[n + 3 * l + j];
+                tempChi = compute_errors(s);
+            } else tempChi = DBL_MAX;
+            double scale = 0;                                                         /* computeScale :182-189 */
+            for (int j = 0; j < nx; j++) {
+                const double bj = j < n ? s->bp[j] : s->bl[j - n];
+                scale += s->x[j] * (lambda * s->x[j] + bj);
+            }
+            scale += 1e-3;
+            rho = ok2 ? (currentChi - tempChi) / scale : -1.0;   /* failed factorisation = rejected step */
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                const double sf = fmax(1. / 3., alpha);
+                lambda *= sf; ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                memcpy(pb->poses, save_pose, sizeof(double) * 7 * (size_t)s->P);   /* pop */
+                memcpy(pb->points, save_pt, sizeof(double) * 3 * (size_t)s->L);
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        done++;
+        if (res) { res->iterations_done++; res->chi2_final = currentChi; res->lambda_final = lambda; }
+        if (qmax == 10 || rho == 0) break;                                            /* Terminate :151 */
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;              /* :154-161 */
+        if (nBad >= 3) break;
+    }
+    free(save_pose); free(save_pt);
+    if (lambda_io) *lambda_io = lambda;
+    return done;
+}
+
+int orc_ba_solve(orc_ba_problem* pb, const orc_ba_options* opt, orc_ba_result* res, uint8_t* edge_outlier)
+{
+    if (!pb || !opt) return -1;
+    ba_t* s = ba_new(pb);
+    orc_ba_result local; if (!res) res = &local;
+    memset(res, 0, sizeof *res);
+    res->chi2_initial = -1;
+    s->huber_delta = opt->huber_delta;
+    lm_optimize(s, opt->iterations, res, 0);
+    if (opt->iterations2 > 0) {                                    /* src/Optimizer.cpp:546-568 */
+        refresh_R(s);
+        for (int e = 0; e < s->E; e++) {
+            const int pi = pb->edge_pose[e], li = pb->edge_point[e];
+            const double* R = s->R + 9 * pi; const double* p = pb->points + 3 * li;
+            const double z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + pb->poses[7 * pi + 6];
+            const double c2 = pb->info[e] * (s->err[2 * e] * s->err[2 * e] + s->err[2 * e + 1] * s->err[2 * e + 1]);
+            if (c2 > opt->outlier_chi2 || !(z > 0.0)) s->active[e] = 0;
+        }
+        s->huber_delta = 0;
+        lm_optimize(s, opt->iterations2, res, 0);
+    }
+    if (edge_outlier) {                                            /* src/Optimizer.cpp:574-588 */
+        refresh_R(s);
+        for (int e = 0; e < s->E; e++) {
+            const int pi = pb->edge_pose[e], li = pb->edge_point[e];
+            const double* R = s->R + 9 * pi; const double* p = pb->points + 3 * li;
+            const double z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + pb->poses[7 * pi + 6];
+            const double c2 = pb->info[e] * (s->err[2 * e] * s->err[2 * e] + s->err[2 * e + 1] * s->err[2 * e + 1]);
+            edge_outlier[e] = (c2 > opt->outlier_chi2 || !(z > 0.0)) ? 1 : 0;
+        }
+    }
+    ba_free(s);
+    return 0;
+}
+
+int orc_ba_reduced_system(const orc_ba_problem* pb, double huber_delta, double lambda,
+                          double* Hschur, double* bschur, int32_t* free_index)
+{
+    ba_t* s = ba_new((orc_ba_problem*)pb);
+    s->huber_delta = huber_delta;
+    compute_errors(s);
+    build_system(s);
+    schur_reduce(s, lambda);
+    const int n = 6 * s->nfree;
+    if (Hschur) memcpy(Hschur, s->Hs, sizeof(double) * (size_t)n * n);
+    if (bschur) memcpy(bschur, s->bs, sizeof(double) * n);
+    if (free_index) for (int i = 0; i < s->P; i++) free_index[i] = s->free_of[i];
+    const int P = s->nfree;
+    ba_free(s);
+    return P;
+}

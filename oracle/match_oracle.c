@@ -1,0 +1,132 @@
+/* match_oracle.c -- CPU restatement of the ORBmatcher hot loop.  TEST INFRASTRUCTURE (see oracle.h).
+ * Reference: cslam/src/ORBmatcher.cpp (both source trees are byte-identical). */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ORBmatcher::DescriptorDistance, ORBmatcher.cpp:1653-1669 -- the bit-hack as written there */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+/* running best / second best of ORBmatcher.cpp:220-245 over every train row */
+void orc_hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt,
+                       int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
+{
+    for (int i = 0; i < nq; i++) {
+        int b1 = 256, bi = -1, b2 = 256;
+        for (int j = 0; j < nt; j++) {
+            const int d = orc_descriptor_distance(q + 32 * (size_t)i, t + 32 * (size_t)j);
+            if (d < b1) { b2 = b1; b1 = d; bi = j; }
+            else if (d < b2) b2 = d;
+        }
+        best_idx[i] = bi; best_dist[i] = b1; second_dist[i] = b2;
+    }
+}
+
+/* ORBmatcher::ComputeThreeMaxima, ORBmatcher.cpp:1607-1648 */
+void orc_three_maxima(const int32_t* hs, int L, int32_t* ind)
+{
+    int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = hs[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+        else if (s > max3) { max3 = s; i3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { i3 = -1; }
+    ind[0] = i1; ind[1] = i2; ind[2] = i3;
+}
+
+/* ORBmatcher::SearchByBoW, ORBmatcher.cpp:178-306 (valid2 == NULL) and :565-698 (valid2 != NULL).
+ * FeatureVector = std::map<NodeId, vector<feature idx>>: nodes ascending, indices ascending inside. */
+typedef struct { int32_t node; int32_t idx; } nf;
+static int nf_cmp(const void* a, const void* b)
+{
+    const nf* x = (const nf*)a; const nf* y = (const nf*)b;
+    if (x->node != y->node) return x->node < y->node ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+int orc_match_bow(float nnratio, int check_ori, int th, int strict_th,
+                  const uint8_t* desc1, const int32_t* node1, const uint8_t* valid1, const float* angle1, int n1,
+                  const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2, const float* angle2, int n2,
+                  int32_t* match12)
+{
+    enum { HISTO = 30 };
+    nf* f1 = (nf*)malloc(sizeof(nf) * (n1 > 0 ? n1 : 1));
+    nf* f2 = (nf*)malloc(sizeof(nf) * (n2 > 0 ? n2 : 1));
+    uint8_t* taken2 = (uint8_t*)calloc(n2 > 0 ? n2 : 1, 1);
+    int32_t* hist = (int32_t*)malloc(sizeof(int32_t) * HISTO * (size_t)(n1 > 0 ? n1 : 1));
+    int32_t hn[HISTO];
+    memset(hn, 0, sizeof hn);
+    int m1 = 0, m2 = 0;
+    for (int i = 0; i < n1; i++) { match12[i] = -1; if (node1[i] >= 0) { f1[m1].node = node1[i]; f1[m1].idx = i; m1++; } }
+    for (int i = 0; i < n2; i++) if (node2[i] >= 0) { f2[m2].node = node2[i]; f2[m2].idx = i; m2++; }
+    qsort(f1, m1, sizeof(nf), nf_cmp);
+    qsort(f2, m2, sizeof(nf), nf_cmp);
+    const float factor = 1.0f / HISTO;                                  /* :191 */
+    int nmatches = 0;
+    int a = 0, b = 0;
+    while (a < m1 && b < m2) {
+        if (f1[a].node == f2[b].node) {
+            int ae = a, be = b;
+            while (ae < m1 && f1[ae].node == f1[a].node) ae++;
+            while (be < m2 && f2[be].node == f2[b].node) be++;
+            for (int i = a; i < ae; i++) {
+                const int idx1 = f1[i].idx;
+                if (!valid1[idx1]) continue;                            /* :212-216 */
+                int bd1 = 256, bi = -1, bd2 = 256;
+                for (int j = b; j < be; j++) {
+                    const int idx2 = f2[j].idx;
+                    if (taken2[idx2]) continue;                         /* :228 / :619 */
+                    if (valid2 && !valid2[idx2]) continue;              /* :619-623 */
+                    const int d = orc_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (d < bd1) { bd2 = bd1; bd1 = d; bi = idx2; }
+                    else if (d < bd2) bd2 = d;
+                }
+                const int pass = strict_th ? (bd1 < th) : (bd1 <= th);  /* :641 vs :247 */
+                if (pass && (float)bd1 < nnratio * (float)bd2) {
+                    match12[idx1] = bi;
+                    taken2[bi] = 1;
+                    if (check_ori) {
+                        float rot = angle1[idx1] - angle2[bi];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);              /* :260: bins 0..12 only, as written */
+                        if (bin == HISTO) bin = 0;
+                        hist[bin * (size_t)n1 + hn[bin]++] = idx1;
+                    }
+                    nmatches++;
+                }
+            }
+            a = ae; b = be;
+        } else if (f1[a].node < f2[b].node) {
+            while (a < m1 && f1[a].node < f2[b].node) a++;               /* lower_bound */
+        } else {
+            while (b < m2 && f2[b].node < f1[a].node) b++;
+        }
+    }
+    if (check_ori) {
+        int32_t ind[3];
+        orc_three_maxima(hn, HISTO, ind);
+        for (int i = 0; i < HISTO; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (int j = 0; j < hn[i]; j++) { match12[hist[i * (size_t)n1 + j]] = -1; nmatches--; }
+        }
+    }
+    free(f1); free(f2); free(taken2); free(hist);
+    return nmatches;
+}

@@ -1,0 +1,86 @@
+/* oracle.h -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * liboracle.so.  Nothing under motioncheck_ccm_slam_amd/ includes, links or
+ * calls it; the product path has no CPU fallback.
+ *
+ * PARITY STATUS:
+ *  - The reference cannot be built here (needs OpenCV, Eigen3, Boost, ROS: absent
+ *    and not installable) and ships no tests, fixtures or golden vectors.
+ *  - FAST, resize, GaussianBlur, fastAtan2, cvRound are OpenCV's (un-vendored,
+ *    un-pinned); SimplicialLDLT / Quaterniond are Eigen's.  Their published
+ *    algorithms are restated from SURVEY.md section 12.  PARITY UNPINNED for
+ *    these primitives.
+ *  - Pinned by known-answer tests derived from the reference text
+ *    (tests/test_oracle_kat.py): feature quotas {217,181,151,126,105,87,73,60},
+ *    umax table, level sizes, Hamming bit-hack == popcount, descriptor bit
+ *    packing, analytic vs numeric Jacobian, Schur == full solve.
+ */
+#ifndef CCM_ORACLE_H
+#define CCM_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int nfeatures; float scale_factor; int nlevels; int ini_th; int min_th; } orc_orb_params;
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } orc_keypoint;
+
+/* ---- ORB ---- */
+int  orc_orb_tables(const orc_orb_params*, float* scale, float* inv_scale, float* sigma2,
+                    float* inv_sigma2, int32_t* nfeat, int32_t* umax);
+int  orc_orb_level_sizes(const orc_orb_params*, int w, int h, int32_t* lw, int32_t* lh);
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
+                          uint8_t* dst, int dw, int dh, int dstride);
+int  orc_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold,
+                  int32_t* xy, int32_t* score, int max);
+void orc_blur7_sigma2(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+float orc_fast_atan2(float y, float x);
+int  orc_round_half_even(double v);
+float orc_ic_angle(const uint8_t* img, int stride, int cx, int cy, const int32_t* umax);
+void orc_orb_descriptor(const uint8_t* blurred, int stride, int cx, int cy, float angle_deg, uint8_t* desc32);
+int  orc_distribute_octree(const int32_t* xy, const int32_t* score, int n, int minX, int maxX,
+                           int minY, int maxY, int N, int32_t* out_idx);
+/* Full operator().  level_out (optional) receives pointers-free copies of the pyramid:
+ * level l at level_out + level_off[l], tight pitch lw[l].  cand_* (optional): FAST candidates of
+ * `cand_level` before the quadtree.  Returns keypoint count or <0. */
+int  orc_orb_extract(const orc_orb_params*, const uint8_t* img, int w, int h, int stride,
+                     orc_keypoint* kps, uint8_t* desc, int max_kps,
+                     uint8_t* level_out, size_t level_out_bytes,
+                     int cand_level, int32_t* cand_xy, int32_t* cand_score, int cand_max, int32_t* cand_n);
+
+/* ---- matcher ---- */
+int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void orc_hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt,
+                       int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+void orc_three_maxima(const int32_t* hist_sizes, int L, int32_t* ind3);
+int  orc_match_bow(float nnratio, int check_ori, int th, int strict_th,
+                   const uint8_t* desc1, const int32_t* node1, const uint8_t* valid1, const float* angle1, int n1,
+                   const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2, const float* angle2, int n2,
+                   int32_t* match12);
+
+/* ---- bundle adjustment ---- */
+typedef struct {
+    int n_poses; double* poses; const uint8_t* fixed; const double* intr;
+    int n_points; double* points;
+    int n_edges; const int32_t* edge_pose; const int32_t* edge_point; const double* obs; const double* info;
+} orc_ba_problem;
+typedef struct { int iterations; double huber_delta; int iterations2; double outlier_chi2; } orc_ba_options;
+typedef struct { int iterations_done; int trials; double chi2_initial, chi2_final, lambda_final; } orc_ba_result;
+int  orc_ba_solve(orc_ba_problem*, const orc_ba_options*, orc_ba_result*, uint8_t* edge_outlier);
+/* building blocks exposed for the known-answer tests */
+void orc_ba_edge(const double* pose7, const double* intr4, const double* pt3, const double* obs2,
+                 double* err2, double* Jpoint_2x3, double* Jpose_2x6);
+void orc_se3_exp_mul(const double* delta6, const double* pose7_in, double* pose7_out);
+void orc_pose_from_mat4f(const float* T16, double* pose7);
+void orc_pose_to_mat4f(const double* pose7, float* T16);
+/* One linearisation at the current state: dense reduced system for checks.
+ * Hschur (6P x 6P, P = free poses, row-major, full symmetric) and bschur; returns P. */
+int  orc_ba_reduced_system(const orc_ba_problem*, double huber_delta, double lambda,
+                           double* Hschur, double* bschur, int32_t* free_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

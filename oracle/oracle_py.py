@@ -1,0 +1,201 @@
+"""ctypes front end of liboracle.so -- TEST INFRASTRUCTURE.
+
+Import only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (motioncheck_ccm_slam_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th", C.c_int), ("min_th", C.c_int)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("poses", C.c_void_p), ("fixed", C.c_void_p), ("intr", C.c_void_p),
+                ("n_points", C.c_int), ("points", C.c_void_p),
+                ("n_edges", C.c_int), ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p),
+                ("obs", C.c_void_p), ("info", C.c_void_p)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("huber_delta", C.c_double), ("iterations2", C.c_int),
+                ("outlier_chi2", C.c_double)]
+
+
+class BaResult(C.Structure):
+    _fields_ = [("iterations_done", C.c_int), ("trials", C.c_int), ("chi2_initial", C.c_double),
+                ("chi2_final", C.c_double), ("lambda_final", C.c_double)]
+
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                     ("octave", "i4"), ("class_id", "i4")])
+
+
+def build(force: bool = False) -> str:
+    path = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "oracle.h")]
+    if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return path
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_fast_atan2.restype = C.c_float
+        _LIB.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _LIB.orc_ic_angle.restype = C.c_float
+        _LIB.orc_round_half_even.argtypes = [C.c_double]
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7) -> OrbParams:
+    return OrbParams(nfeatures, scale, nlevels, ini, mn)
+
+
+def orb_tables(par: OrbParams):
+    n = par.nlevels
+    sc = np.zeros(n, "f4"); inv = np.zeros(n, "f4"); s2 = np.zeros(n, "f4"); is2 = np.zeros(n, "f4")
+    nf = np.zeros(n, "i4"); um = np.zeros(16, "i4")
+    rc = lib().orc_orb_tables(C.byref(par), _p(sc), _p(inv), _p(s2), _p(is2), _p(nf), _p(um))
+    assert rc == 0
+    return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, nfeat=nf, umax=um)
+
+
+def level_sizes(par: OrbParams, w: int, h: int):
+    lw = np.zeros(par.nlevels, "i4"); lh = np.zeros(par.nlevels, "i4")
+    lib().orc_orb_level_sizes(C.byref(par), w, h, _p(lw), _p(lh))
+    return lw, lh
+
+
+def resize(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+    return dst
+
+
+def fast(img: np.ndarray, th: int, cap: int = 1 << 16):
+    img = np.ascontiguousarray(img, np.uint8)
+    xy = np.zeros((cap, 2), "i4"); sc = np.zeros(cap, "i4")
+    n = lib().orc_fast9_16(_p(img), img.shape[1], img.shape[0], img.shape[1], th, _p(xy), _p(sc), cap)
+    assert n <= cap
+    return xy[:n].copy(), sc[:n].copy()
+
+
+def blur(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_blur7_sigma2(_p(img), img.shape[1], img.shape[0], img.shape[1], _p(out), img.shape[1])
+    return out
+
+
+def orb_extract(par: OrbParams, img: np.ndarray, max_kps: int = 4096, cand_level: int = -1, want_levels=False):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    kps = np.zeros(max_kps, KP_DTYPE); desc = np.zeros((max_kps, 32), np.uint8)
+    lw, lh = level_sizes(par, w, h)
+    tot = int((lw.astype(np.int64) * lh).sum())
+    levels = np.zeros(tot, np.uint8) if want_levels else None
+    cap = 1 << 18
+    cxy = np.zeros((cap, 2), "i4"); csc = np.zeros(cap, "i4"); cn = C.c_int32(0)
+    n = lib().orc_orb_extract(C.byref(par), _p(img), w, h, w, _p(kps), _p(desc), max_kps,
+                              _p(levels), C.c_size_t(tot if want_levels else 0),
+                              cand_level, _p(cxy), _p(csc), cap, C.byref(cn))
+    assert n >= 0, n
+    out = dict(kps=kps[:n].copy(), desc=desc[:n].copy())
+    if cand_level >= 0:
+        out["cand_xy"] = cxy[:cn.value].copy(); out["cand_score"] = csc[:cn.value].copy()
+    if want_levels:
+        lv, off = [], 0
+        for l in range(par.nlevels):
+            lv.append(levels[off:off + lw[l] * lh[l]].reshape(lh[l], lw[l])); off += lw[l] * lh[l]
+        out["levels"] = lv
+    return out
+
+
+def distance(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def hamming_match(q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    nq, nt = len(q), len(t)
+    bi = np.zeros(nq, "i4"); bd = np.zeros(nq, "i4"); sd = np.zeros(nq, "i4")
+    lib().orc_hamming_match(_p(q), nq, _p(t), nt, _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def match_bow(nnratio, check_ori, th, strict, d1, node1, valid1, ang1, d2, node2, valid2, ang2):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    node1 = np.ascontiguousarray(node1, "i4"); node2 = np.ascontiguousarray(node2, "i4")
+    valid1 = np.ascontiguousarray(valid1, np.uint8)
+    valid2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    ang1 = np.ascontiguousarray(ang1, "f4"); ang2 = np.ascontiguousarray(ang2, "f4")
+    m = np.zeros(len(d1), "i4")
+    n = lib().orc_match_bow(C.c_float(nnratio), int(check_ori), int(th), int(strict),
+                            _p(d1), _p(node1), _p(valid1), _p(ang1), len(d1),
+                            _p(d2), _p(node2), _p(valid2), _p(ang2), len(d2), _p(m))
+    return n, m
+
+
+def _ba_problem(g):
+    keep = dict(
+        poses=np.ascontiguousarray(g["poses"], "f8").copy(), fixed=np.ascontiguousarray(g["fixed"], np.uint8),
+        intr=np.ascontiguousarray(g["intr"], "f8"), points=np.ascontiguousarray(g["points"], "f8").copy(),
+        edge_pose=np.ascontiguousarray(g["edge_pose"], "i4"), edge_point=np.ascontiguousarray(g["edge_point"], "i4"),
+        obs=np.ascontiguousarray(g["obs"], "f8"), info=np.ascontiguousarray(g["info"], "f8"))
+    pb = BaProblem(len(keep["poses"]), _p(keep["poses"]), _p(keep["fixed"]), _p(keep["intr"]),
+                   len(keep["points"]), _p(keep["points"]), len(keep["edge_pose"]),
+                   _p(keep["edge_pose"]), _p(keep["edge_point"]), _p(keep["obs"]), _p(keep["info"]))
+    return pb, keep
+
+
+def ba_solve(g, iterations, huber_delta, iterations2=0, outlier_chi2=5.991):
+    pb, keep = _ba_problem(g)
+    opt = BaOptions(iterations, huber_delta, iterations2, outlier_chi2)
+    res = BaResult()
+    outl = np.zeros(len(keep["edge_pose"]), np.uint8)
+    rc = lib().orc_ba_solve(C.byref(pb), C.byref(opt), C.byref(res), _p(outl))
+    assert rc == 0
+    return dict(poses=keep["poses"], points=keep["points"], outlier=outl,
+                iterations_done=res.iterations_done, trials=res.trials, chi2_initial=res.chi2_initial,
+                chi2_final=res.chi2_final, lambda_final=res.lambda_final)
+
+
+def ba_edge(pose7, intr4, pt3, obs2):
+    e = np.zeros(2); A = np.zeros((2, 3)); B = np.zeros((2, 6))
+    a = [np.ascontiguousarray(v, "f8") for v in (pose7, intr4, pt3, obs2)]
+    lib().orc_ba_edge(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(e), _p(A), _p(B))
+    return e, A, B
+
+
+def se3_exp_mul(delta6, pose7):
+    d = np.ascontiguousarray(delta6, "f8"); p = np.ascontiguousarray(pose7, "f8"); o = np.zeros(7)
+    lib().orc_se3_exp_mul(_p(d), _p(p), _p(o))
+    return o
+
+
+def ba_reduced_system(g, huber_delta, lam):
+    pb, keep = _ba_problem(g)
+    nfree = int((keep["fixed"] == 0).sum())
+    H = np.zeros((6 * nfree, 6 * nfree)); b = np.zeros(6 * nfree); fi = np.zeros(len(keep["poses"]), "i4")
+    P = lib().orc_ba_reduced_system(C.byref(pb), C.c_double(huber_delta), C.c_double(lam), _p(H), _p(b), _p(fi))
+    assert P == nfree
+    return H, b, fi

@@ -1,0 +1,57 @@
+// ccm_ctx.cpp -- context lifetime and error reporting for the C ABI (include/ccm_hot.h).
+#include "ccm_internal.h"
+#include <cstdarg>
+
+int ccm_fail(ccm_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+extern "C" {
+
+int ccm_abi_version(void) { return CCM_ABI_VERSION; }
+
+ccm_ctx* ccm_create(int device, int flags)
+{
+    (void)flags;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    ccm_ctx* c = new (std::nothrow) ccm_ctx();
+    if (!c) return nullptr;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    return c;
+}
+
+void ccm_destroy(ccm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_state_free(c);
+    orb_state_free(c->orb);
+    match_state_free(c->match);
+    ba_state_free(c->ba);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* ccm_last_error(const ccm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int ccm_sync(ccm_ctx* c)
+{
+    if (!c) return CCM_E_ARG;
+    CCM_HIP(c, hipStreamSynchronize(c->stream));
+    return CCM_OK;
+}
+
+void* ccm_stream(ccm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+}  // extern "C"

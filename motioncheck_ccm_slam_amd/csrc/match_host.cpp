@@ -1,0 +1,203 @@
+// match_host.cpp -- C ABI of the matcher (include/ccm_hot.h): brute-force Hamming search and
+// ORBmatcher::SearchByBoW (cslam/src/ORBmatcher.cpp:178-306, 565-698).
+#include "ccm_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+void match_launch_bf(hipStream_t, const uint8_t* q, long long q_pair_bytes, const uint8_t* t, long long t_pair_bytes,
+                     int nq, int nt, int n_pairs, const int* nq_n, const int* nt_n, int* bi, int* bd, int* sd);
+void match_launch_ranges(hipStream_t, const uint8_t* d1, const uint8_t* d2, const int* order2, const int* start,
+                         const int* len, const long long* off, int n1, unsigned short* dist);
+
+struct MatchState {
+    DevBuf q, t, nqn, ntn, bi, bd, sd;          // brute force staging
+    DevBuf d1, d2, order2, start, len, off, dist; // BoW staging
+};
+void match_state_free(MatchState* s)
+{
+    if (!s) return;
+    DevBuf* all[] = { &s->q, &s->t, &s->nqn, &s->ntn, &s->bi, &s->bd, &s->sd, &s->d1, &s->d2, &s->order2, &s->start, &s->len, &s->off, &s->dist };
+    for (DevBuf* b : all) b->release();
+    delete s;
+}
+
+extern "C" {
+
+// ORBmatcher::DescriptorDistance, ORBmatcher.cpp:1653-1669
+int ccm_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t x, y;
+        std::memcpy(&x, a + 4 * i, 4);
+        std::memcpy(&y, b + 4 * i, 4);
+        d += __builtin_popcount(x ^ y);
+    }
+    return d;
+}
+
+// ORBmatcher.cpp:247-249 (Frame overload) / :641-643 (KF-KF overload)
+int ccm_ratio_test(int best_dist, int second_dist, float nnratio, int th, int strict)
+{
+    const bool pass = strict ? (best_dist < th) : (best_dist <= th);
+    return pass && (static_cast<float>(best_dist) < nnratio * static_cast<float>(second_dist)) ? 1 : 0;
+}
+
+int ccm_hamming_match_dev(ccm_ctx* c, const uint8_t* q_dev, int nq, size_t q_pair_stride, const uint8_t* t_dev, int nt,
+                          size_t t_pair_stride, int n_pairs, const int32_t* nq_n_dev, const int32_t* nt_n_dev,
+                          int32_t* best_idx_dev, int32_t* best_dist_dev, int32_t* second_dist_dev)
+{
+    if (!c) return CCM_E_ARG;
+    if (n_pairs == 0 || nq == 0) return CCM_OK;
+    if (n_pairs < 0 || nq < 0 || nt < 0 || nt > 65535 || !q_dev || (!t_dev && nt > 0) || !best_idx_dev || !best_dist_dev || !second_dist_dev)
+        return ccm_fail(c, CCM_E_ARG, "bad matcher arguments (nt must be <= 65535)");
+    if (((uintptr_t)q_dev | (uintptr_t)t_dev) & 15) return ccm_fail(c, CCM_E_ARG, "descriptor arrays must be 16-byte aligned");
+    CCM_HIP(c, hipSetDevice(c->device));
+    match_launch_bf(c->stream, q_dev, (long long)q_pair_stride * 32, t_dev, (long long)t_pair_stride * 32, nq, nt, n_pairs,
+                    nq_n_dev, nt_n_dev, best_idx_dev, best_dist_dev, second_dist_dev);
+    CCM_HIP(c, hipGetLastError());
+    return CCM_OK;
+}
+
+int ccm_hamming_match(ccm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int n_pairs, const int32_t* nq_n,
+                      const int32_t* nt_n, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
+{
+    if (!c) return CCM_E_ARG;
+    if (n_pairs == 0 || nq == 0) return CCM_OK;
+    if (n_pairs < 0 || nq < 0 || nt < 0 || !q || (!t && nt > 0) || !best_idx || !best_dist || !second_dist)
+        return ccm_fail(c, CCM_E_ARG, "bad matcher arguments");
+    CCM_HIP(c, hipSetDevice(c->device));
+    if (!c->match) c->match = new MatchState();
+    MatchState& M = *c->match;
+    const size_t qb = (size_t)n_pairs * nq * 32, tb = (size_t)n_pairs * nt * 32, ob = (size_t)n_pairs * nq * 4;
+    CCM_RESERVE(c, M.q, qb); CCM_RESERVE(c, M.t, std::max<size_t>(tb, 32));
+    CCM_RESERVE(c, M.bi, ob); CCM_RESERVE(c, M.bd, ob); CCM_RESERVE(c, M.sd, ob);
+    CCM_RESERVE(c, M.nqn, (size_t)n_pairs * 4); CCM_RESERVE(c, M.ntn, (size_t)n_pairs * 4);
+    CCM_HIP(c, hipMemcpyAsync(M.q.p, q, qb, hipMemcpyHostToDevice, c->stream));
+    if (tb) CCM_HIP(c, hipMemcpyAsync(M.t.p, t, tb, hipMemcpyHostToDevice, c->stream));
+    if (nq_n) CCM_HIP(c, hipMemcpyAsync(M.nqn.p, nq_n, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    if (nt_n) CCM_HIP(c, hipMemcpyAsync(M.ntn.p, nt_n, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    int rc = ccm_hamming_match_dev(c, M.q.as<uint8_t>(), nq, nq, M.t.as<uint8_t>(), nt, nt, n_pairs,
+                                   nq_n ? M.nqn.as<int32_t>() : nullptr, nt_n ? M.ntn.as<int32_t>() : nullptr,
+                                   M.bi.as<int32_t>(), M.bd.as<int32_t>(), M.sd.as<int32_t>());
+    if (rc) return rc;
+    CCM_HIP(c, hipMemcpyAsync(best_idx, M.bi.p, ob, hipMemcpyDeviceToHost, c->stream));
+    CCM_HIP(c, hipMemcpyAsync(best_dist, M.bd.p, ob, hipMemcpyDeviceToHost, c->stream));
+    CCM_HIP(c, hipMemcpyAsync(second_dist, M.sd.p, ob, hipMemcpyDeviceToHost, c->stream));
+    CCM_HIP(c, hipStreamSynchronize(c->stream));
+    return CCM_OK;
+}
+
+// ORBmatcher::ComputeThreeMaxima, ORBmatcher.cpp:1607-1648
+static void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, const int32_t* node1, const uint8_t* valid1,
+                  const float* angle1, int n1, const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2,
+                  const float* angle2, int n2, int32_t* match12)
+{
+    if (!c || !o) return CCM_E_ARG;
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && (!desc1 || !node1 || !valid1 || !match12)) || (n2 > 0 && (!desc2 || !node2)) ||
+        (o->check_ori && n1 > 0 && n2 > 0 && (!angle1 || !angle2)))
+        return ccm_fail(c, CCM_E_ARG, "bad SearchByBoW arguments");
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    CCM_HIP(c, hipSetDevice(c->device));
+    if (!c->match) c->match = new MatchState();
+    MatchState& M = *c->match;
+    // FeatureVector order: node ascending, feature index ascending inside a node (DBoW2 fills it so)
+    std::vector<int> ord1(n1), ord2(n2);
+    std::iota(ord1.begin(), ord1.end(), 0); std::iota(ord2.begin(), ord2.end(), 0);
+    auto by_node = [](const int32_t* node) { return [node](int a, int b) { return node[a] != node[b] ? node[a] < node[b] : a < b; }; };
+    std::stable_sort(ord1.begin(), ord1.end(), by_node(node1));
+    std::stable_sort(ord2.begin(), ord2.end(), by_node(node2));
+    // per side-1 feature: the slice of ord2 holding its node (features without a node have id < 0)
+    std::vector<int> start(n1, 0), len(n1, 0);
+    std::vector<long long> off(n1 + 1, 0);
+    {
+        size_t b = 0;
+        for (size_t a = 0; a < ord1.size();) {
+            const int nd = node1[ord1[a]];
+            size_t ae = a; while (ae < ord1.size() && node1[ord1[ae]] == nd) ae++;
+            while (b < ord2.size() && node2[ord2[b]] < nd) b++;
+            size_t be = b; while (be < ord2.size() && node2[ord2[be]] == nd) be++;
+            if (nd >= 0) for (size_t i = a; i < ae; i++) if (valid1[ord1[i]]) { start[ord1[i]] = (int)b; len[ord1[i]] = (int)(be - b); }
+            a = ae; b = be;
+        }
+    }
+    for (int i = 0; i < n1; i++) off[i + 1] = off[i] + len[i];
+    const long long total = off[n1];
+    std::vector<unsigned short> dist((size_t)std::max<long long>(total, 1));
+    if (total > 0) {
+        CCM_RESERVE(c, M.d1, (size_t)n1 * 32); CCM_RESERVE(c, M.d2, (size_t)n2 * 32);
+        CCM_RESERVE(c, M.order2, (size_t)n2 * 4); CCM_RESERVE(c, M.start, (size_t)n1 * 4); CCM_RESERVE(c, M.len, (size_t)n1 * 4);
+        CCM_RESERVE(c, M.off, (size_t)(n1 + 1) * 8); CCM_RESERVE(c, M.dist, (size_t)total * 2);
+        CCM_HIP(c, hipMemcpyAsync(M.d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
+        CCM_HIP(c, hipMemcpyAsync(M.d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream));
+        CCM_HIP(c, hipMemcpyAsync(M.order2.p, ord2.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, c->stream));
+        CCM_HIP(c, hipMemcpyAsync(M.start.p, start.data(), (size_t)n1 * 4, hipMemcpyHostToDevice, c->stream));
+        CCM_HIP(c, hipMemcpyAsync(M.len.p, len.data(), (size_t)n1 * 4, hipMemcpyHostToDevice, c->stream));
+        CCM_HIP(c, hipMemcpyAsync(M.off.p, off.data(), (size_t)(n1 + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        match_launch_ranges(c->stream, M.d1.as<uint8_t>(), M.d2.as<uint8_t>(), M.order2.as<int>(), M.start.as<int>(),
+                            M.len.as<int>(), M.off.as<long long>(), n1, M.dist.as<unsigned short>());
+        CCM_HIP(c, hipGetLastError());
+        CCM_HIP(c, hipMemcpyAsync(dist.data(), M.dist.p, (size_t)total * 2, hipMemcpyDeviceToHost, c->stream));
+        CCM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    // greedy acceptance in the reference's visiting order (sequential by construction: a side-2
+    // feature matched earlier is skipped later, ORBmatcher.cpp:228-229 / :619)
+    const int HISTO = 30;
+    std::vector<int> rot[HISTO];
+    const float factor = 1.0f / HISTO;
+    std::vector<uint8_t> taken(n2, 0);
+    int nmatches = 0;
+    for (int a = 0; a < n1; a++) {
+        const int i1 = ord1[a];
+        if (node1[i1] < 0 || !valid1[i1] || len[i1] == 0) continue;
+        int bd1 = 256, bi = -1, bd2 = 256;
+        const unsigned short* d = dist.data() + off[i1];
+        for (int k = 0; k < len[i1]; k++) {
+            const int i2 = ord2[start[i1] + k];
+            if (taken[i2]) continue;
+            if (valid2 && !valid2[i2]) continue;
+            const int dd = d[k];
+            if (dd < bd1) { bd2 = bd1; bd1 = dd; bi = i2; }
+            else if (dd < bd2) bd2 = dd;
+        }
+        if (ccm_ratio_test(bd1, bd2, o->nnratio, o->th, o->strict_th)) {
+            match12[i1] = bi;
+            taken[bi] = 1;
+            if (o->check_ori) {
+                float r = angle1[i1] - angle2[bi];
+                if (r < 0.0) r += 360.0f;
+                int bin = (int)std::round(r * factor);      // 1/HISTO_LENGTH as in the reference: bins 0..12
+                if (bin == HISTO) bin = 0;
+                rot[bin].push_back(i1);
+            }
+            nmatches++;
+        }
+    }
+    if (o->check_ori) {
+        int i1, i2, i3;
+        three_maxima(rot, HISTO, i1, i2, i3);
+        for (int i = 0; i < HISTO; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx : rot[i]) { match12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+}  // extern "C"

@@ -1,0 +1,735 @@
+// orb_kernels.hip -- CDNA4 (gfx950) kernels of the ORB extractor.
+//
+// Pipeline per batch (all frames of the batch in every launch):
+//   k_pyr_resize  x (nlevels-1)   cv::resize INTER_LINEAR 8u          ORBextractor.cpp:1293
+//   k_fast_score                  FAST-9/16 corner score of every px  :978-984 (cv::FAST)
+//   k_cell_nms                    per-cell threshold choice + 3x3 NMS :957-998
+//   k_octree                      DistributeOctTree                   :707-931
+//   k_orient_desc                 IC_Angle + 7x7 blur + rBRIEF        :68-95, :1259, :100-316
+// Wavefront = 64 everywhere; ballots are 64-bit.
+#include <hip/hip_runtime.h>
+#include "orb_types.h"
+#include "../../include/ccm_orb_pattern.h"
+#include "../../include/ccm_sincos.h"
+#include "../../include/ccm_hot.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// inclusive wave prefix sum
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(v, d, 64);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pyr_resize: one thread = 4 horizontally adjacent output pixels of one row.
+// Fixed-point bilinear exactly as cv::resize(INTER_LINEAR) for 8-bit data:
+// weights are the host-made 11-bit tables, horizontal pass int32, vertical pass
+// ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.
+__global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom* __restrict__ g, int level)
+{
+    const OrbLevel& D = g->lv[level];
+    const OrbLevel& S = g->lv[level - 1];
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.z;
+    if (y >= D.h || x4 >= D.w) return;
+    const uint8_t* src = S.img + (long long)f * S.plane;
+    uint8_t* dst = const_cast<uint8_t*>(D.img) + (long long)f * D.plane + (long long)y * D.pitch;
+    const int sy0 = D.yofs[y];
+    const int sy1 = min(sy0 + 1, S.h - 1);
+    const int b0 = D.yab[2 * y], b1 = D.yab[2 * y + 1];
+    const uint8_t* r0p = src + (long long)sy0 * S.pitch;
+    const uint8_t* r1p = src + (long long)sy1 * S.pitch;
+    unsigned out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = min(x4 + i, D.w - 1);
+        const int sx0 = D.xofs[x];
+        const int sx1 = min(sx0 + 1, S.w - 1);
+        const int a0 = D.xab[2 * x], a1 = D.xab[2 * x + 1];
+        const int r0 = r0p[sx0] * a0 + r0p[sx1] * a1;
+        const int r1 = r1p[sx0] * a0 + r1p[sx1] * a1;
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        out |= (unsigned)(v & 255) << (8 * i);
+    }
+    // our level buffers have pitch % 64 == 0 and a 256-byte aligned base: the dword store is aligned
+    *reinterpret_cast<unsigned*>(dst + x4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 score: the largest threshold t for which the pixel is still a corner,
+// i.e. max over the 16 arcs of 9 contiguous ring pixels of min(v - ring) (ring darker) or of
+// min(ring - v) (ring brighter), minus one.  A pixel is a corner at threshold T iff score >= T, so
+// one score map serves iniThFAST and the minThFAST fallback.  Equivalent to cv::FAST's
+// cornerScore<16> for every detected corner (checked against the oracle's literal restatement).
+__host__ __device__ inline int fast_score16(int v, const int* r)
+{
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - r[k];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int a = d[k], b = d[(k + 1) & 15], c = d[(k + 2) & 15];
+        lo3[k] = min(a, min(b, c));
+        hi3[k] = max(a, max(b, c));
+    }
+    int A = -256, B = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        A = max(A, min(lo3[k], min(lo3[(k + 3) & 15], lo3[(k + 6) & 15])));
+        B = min(B, max(hi3[k], max(hi3[(k + 3) & 15], hi3[(k + 6) & 15])));
+    }
+    return max(A, -B) - 1;
+}
+
+#define ST_W 64
+#define ST_H 16
+#define ST_LW 72           // 64 + 2*4 (3-px halo rounded up to a dword on each side)
+#define ST_LH 22           // 16 + 2*3
+
+__global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ g)
+{
+    __shared__ uint8_t tile[ST_LH][ST_LW];
+    // flattened tile index -> level
+    int t = blockIdx.x, level = 0;
+    for (int l = 1; l < g->nlevels; l++)
+        if (t >= g->lv[l].tile_first) level = l;
+    const OrbLevel& L = g->lv[level];
+    t -= L.tile_first;
+    const int tx0 = (t % L.tiles_x) * ST_W, ty0 = (t / L.tiles_x) * ST_H;
+    const int f = blockIdx.y;
+    const uint8_t* img = L.img + (long long)f * L.plane;
+    // stage (clamped) pixels; clamped duplicates are only read by pixels whose score is not needed
+    for (int i = threadIdx.x; i < ST_LH * ST_LW; i += 256) {
+        const int ly = i / ST_LW, lx = i - ly * ST_LW;
+        const int gy = min(max(ty0 + ly - 3, 0), L.h - 1);
+        const int gx = min(max(tx0 + lx - 4, 0), L.w - 1);
+        tile[ly][lx] = img[(long long)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    const int px = (threadIdx.x & 15) * 4, py = threadIdx.x >> 4;
+    const int gy = ty0 + py;
+    const int t_lo = min(g->ini_th, g->min_th);
+    unsigned out = 0;
+    if (gy >= ORB_EDGE && gy < L.h - ORB_EDGE) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int gx = tx0 + px + i;
+            if (gx < ORB_EDGE || gx >= L.w - ORB_EDGE) continue;
+            const int cy = py + 3, cx = px + i + 4;
+            const int v = tile[cy][cx];
+            // every 9-arc contains ring pixel k or k+8: both within +-t_lo -> never a corner
+            const int n = tile[cy + 3][cx], s = tile[cy - 3][cx];
+            const int e = tile[cy][cx + 3], w = tile[cy][cx - 3];
+            const bool rej = (abs(v - n) <= t_lo && abs(v - s) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo);
+            if (rej) continue;
+            int r[16];
+            r[0] = n;                   r[1] = tile[cy + 3][cx + 1];  r[2] = tile[cy + 2][cx + 2];
+            r[3] = tile[cy + 1][cx + 3]; r[4] = e;                    r[5] = tile[cy - 1][cx + 3];
+            r[6] = tile[cy - 2][cx + 2]; r[7] = tile[cy - 3][cx + 1]; r[8] = s;
+            r[9] = tile[cy - 3][cx - 1]; r[10] = tile[cy - 2][cx - 2]; r[11] = tile[cy - 1][cx - 3];
+            r[12] = w;                  r[13] = tile[cy + 1][cx - 3]; r[14] = tile[cy + 2][cx - 2];
+            r[15] = tile[cy + 3][cx - 1];
+            const int sc = fast_score16(v, r);
+            if (sc >= t_lo && sc > 0) out |= (unsigned)sc << (8 * i);
+        }
+    }
+    if (gy < L.h && tx0 + px < L.spitch)
+        *reinterpret_cast<unsigned*>(L.smap + (long long)f * L.splane + (long long)gy * L.spitch + tx0 + px) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cell_nms: one wave per FAST cell.  Reproduces, on the cell's sub-image, what
+//   FAST(sub, iniThFAST, nms=true); if empty FAST(sub, minThFAST, nms=true)
+// returns: detection area = sub-image minus a 3-px margin; scores of non-corners and of pixels
+// outside the detection area count as 0; keep a corner iff its score is strictly greater than its 8
+// neighbours'; output in row-major order.  Candidates go to the cell's slot range as
+// score<<24 | y<<12 | x with x,y relative to minBorderX/Y (the coordinates of vToDistributeKeys).
+#define NMS_PITCH 64      // cells are at most 65 px wide (wCell <= 59, +6): 59+2 columns with the zero ring
+#define NMS_ROWS 62
+__global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g, const OrbCell* __restrict__ cells,
+                                                  unsigned* __restrict__ slots, int* __restrict__ cell_count)
+{
+    __shared__ uint8_t lds[4][NMS_ROWS * NMS_PITCH];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int ci = blockIdx.x * 4 + wv;
+    if (ci >= g->ncells) return;
+    const int f = blockIdx.y;
+    const OrbCell c = cells[ci];
+    const OrbLevel& L = g->lv[c.level];
+    const int rx0 = c.x0 + 3, ry0 = c.y0 + 3, rw = c.cw - 6, rh = c.ch - 6;
+    int* count_out = cell_count + (long long)f * g->ncells + ci;
+    if (rw <= 0 || rh <= 0) { if (lane == 0) *count_out = 0; return; }
+    uint8_t* T = lds[wv];
+    const uint8_t* sm = L.smap + (long long)f * L.splane;
+    const int lw = rw + 2, lh = rh + 2;
+    // load raw scores with a zero ring
+    for (int i = lane; i < lw * lh; i += 64) {
+        const int yy = i / lw, xx = i - yy * lw;
+        int s = 0;
+        if (yy >= 1 && yy <= rh && xx >= 1 && xx <= rw)
+            s = sm[(long long)(ry0 + yy - 1) * L.spitch + rx0 + xx - 1];
+        T[yy * NMS_PITCH + xx] = (uint8_t)s;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's LDS stores have landed
+    __builtin_amdgcn_wave_barrier();
+    unsigned* out = slots + (long long)f * g->slots_per_frame + c.slot_first;
+    const int relx = rx0 - ORB_BORDER, rely = ry0 - ORB_BORDER;
+    int n = 0;
+    // First iniThFAST; the fallback to minThFAST happens when FAST returned NO KEYPOINT, i.e. after
+    // non-max suppression (:981) -- corners that suppress each other with equal scores also trigger it.
+    for (int attempt = 0; attempt < 2 && n == 0; attempt++) {
+        const int th = attempt == 0 ? g->ini_th : g->min_th;
+        for (int base = 0; base < rw * rh; base += 64) {
+            const int i = base + lane;
+            bool keep = false;
+            int yy = 0, xx = 0, s = 0;
+            if (i < rw * rh) {
+                yy = i / rw; xx = i - yy * rw;
+                const uint8_t* p = &T[(yy + 1) * NMS_PITCH + xx + 1];
+                s = p[0];
+                if (s >= th && s > 0) {
+                    // scores below the threshold belong to non-corners and count as 0
+#define NB(o) ((int)p[o] >= th ? (int)p[o] : 0)
+                    keep = s > NB(-1) && s > NB(1) &&
+                           s > NB(-NMS_PITCH - 1) && s > NB(-NMS_PITCH) && s > NB(-NMS_PITCH + 1) &&
+                           s > NB(NMS_PITCH - 1) && s > NB(NMS_PITCH) && s > NB(NMS_PITCH + 1);
+#undef NB
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = n + __popcll(m & lanemask_lt());
+                if (pos < c.slot_cap)
+                    out[pos] = ((unsigned)s << 24) | ((unsigned)(rely + yy) << 12) | (unsigned)(relx + xx);
+            }
+            n += __popcll(m);
+        }
+    }
+    if (lane == 0) *count_out = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_octree: DistributeOctTree (ORBextractor.cpp:707-931), one wave per (frame, level).
+//
+// The reference keeps nodes in a std::list, inserting children with push_front and erasing the
+// parent.  Equivalent array form used here: after a pass in which the nodes P_0..P_{m-1} are divided
+// in processing order, the new list is   reverse(children in creation order) ++ (old list minus the
+// divided nodes).  Keys stay grouped by node inside a ping-pong scratch array; dividing a node is a
+// stable 4-way partition of its key range (DivideNode pushes keys in order, :681-695).
+// "Full" passes divide every node holding more than one key, in list order (:774-833).  Once
+// size + 3*nToExpand > N the reference switches to dividing in descending (size, address) order and
+// stops as soon as size >= N (:841-905); equal sizes are ordered by creation (later first), the
+// same deterministic replacement for the address order that the oracle documents.
+struct OctNodes {
+    int* first; int* count;
+    short* x0; short* y0; short* x1; short* y1;
+    uint8_t* buf;
+};
+#define OCT_SET_BYTES 20       // per node in one OctNodes set (17 used)
+#define OCT_NODE_LDS 72        // total LDS bytes per list slot: 2 sets + cc[4] + ord + cbase + mark + gain
+
+__device__ __forceinline__ OctNodes oct_carve(char* base, int cap)
+{
+    OctNodes n;
+    n.first = reinterpret_cast<int*>(base);              base += 4 * cap;
+    n.count = reinterpret_cast<int*>(base);              base += 4 * cap;
+    n.x0 = reinterpret_cast<short*>(base);               base += 2 * cap;
+    n.y0 = reinterpret_cast<short*>(base);               base += 2 * cap;
+    n.x1 = reinterpret_cast<short*>(base);               base += 2 * cap;
+    n.y1 = reinterpret_cast<short*>(base);               base += 2 * cap;
+    n.buf = reinterpret_cast<uint8_t*>(base);
+    return n;
+}
+
+__device__ __forceinline__ int key_x(unsigned k) { return (int)(k & 0xFFFu); }
+__device__ __forceinline__ int key_y(unsigned k) { return (int)((k >> 12) & 0xFFFu); }
+
+// The block is ONE wave: this orders the LDS and global accesses of its lanes between phases.
+__device__ __forceinline__ void wave_sync_mem()
+{
+    __threadfence_block();
+    __syncthreads();
+}
+
+__device__ __forceinline__ int oct_nonempty(const int* cc, int p)
+{
+    return (cc[4 * p] > 0) + (cc[4 * p + 1] > 0) + (cc[4 * p + 2] > 0) + (cc[4 * p + 3] > 0);
+}
+
+__global__ __launch_bounds__(64) void k_octree(const OrbGeom* __restrict__ g, const OrbCell* __restrict__ cells,
+                                               const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
+                                               unsigned* keysA, unsigned* keysB,
+                                               unsigned* __restrict__ out, int* __restrict__ out_count,
+                                               int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int level = blockIdx.x, f = blockIdx.y, lane = lane_id();
+    const OrbLevel& L = g->lv[level];
+    const int cap = g->list_cap;                                          // multiple of 16
+    OctNodes cur = oct_carve(smem, cap);
+    OctNodes nxt = oct_carve(smem + (size_t)cap * OCT_SET_BYTES, cap);
+    int* cc = reinterpret_cast<int*>(smem + (size_t)cap * 2 * OCT_SET_BYTES);   // [cap][4] child key counts
+    int* ord = cc + 4 * cap;          // processing order -> list position
+    int* cbase = ord + cap;           // creation index of the first child of the k-th divided node
+    int* mark = cbase + cap;          // 0 = survivor, k+1 = divided as the k-th
+    int* gain = mark + cap;           // careful mode: list growth per candidate, in rank order
+    int* shared_len = gain + cap;     // one uniform word
+
+    unsigned* kb[2] = { keysA + (long long)f * g->keys_per_frame + L.key_first,
+                        keysB + (long long)f * g->keys_per_frame + L.key_first };
+    const int N = L.quota;
+    int* ocount = out_count + (long long)f * g->nlevels + level;
+
+    // ---- gather this level's candidates in cell-major order into kb[0]
+    const int* ccount = cell_count + (long long)f * g->ncells + L.cell_first;
+    const unsigned* fslots = slots + (long long)f * g->slots_per_frame;
+    int total = 0;
+    for (int base = 0; base < L.ncells; base += 64) {
+        const int ci = base + lane;
+        const int cnt = ci < L.ncells ? ccount[ci] : 0;
+        const int incl = wave_incl_scan(cnt);
+        const int dst = total + incl - cnt;
+        if (cnt > 0) {
+            const unsigned* s = fslots + cells[L.cell_first + ci].slot_first;
+            for (int k = 0; k < cnt; k++)
+                if (dst + k < L.key_cap) kb[0][dst + k] = s[k];
+        }
+        total += __shfl(incl, 63, 64);
+    }
+    if (total > L.key_cap) { if (lane == 0) atomicOr(status, 1); total = L.key_cap; }
+    const int n = total;
+    if (n == 0 || N <= 0) { if (lane == 0) *ocount = 0; return; }
+    wave_sync_mem();
+
+    // ---- roots (:711-753): stable partition of all keys by (int)(x / hX) into kb[1]
+    const int R = L.roots;
+    int rcount[ORB_MAX_ROOTS];
+#pragma unroll
+    for (int r = 0; r < ORB_MAX_ROOTS; r++) rcount[r] = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        int r = -1;
+        if (i < n) { r = (int)((float)key_x(kb[0][i]) / L.hx); r = min(r, R - 1); }
+#pragma unroll
+        for (int q = 0; q < ORB_MAX_ROOTS; q++) rcount[q] += __popcll(__ballot(r == q));
+    }
+    int rbase[ORB_MAX_ROOTS];
+    {
+        int acc = 0;
+#pragma unroll
+        for (int r = 0; r < ORB_MAX_ROOTS; r++) { rbase[r] = acc; acc += rcount[r]; }
+    }
+    {
+        int run[ORB_MAX_ROOTS];
+#pragma unroll
+        for (int r = 0; r < ORB_MAX_ROOTS; r++) run[r] = rbase[r];
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            int r = -1; unsigned key = 0;
+            if (i < n) { key = kb[0][i]; r = (int)((float)key_x(key) / L.hx); r = min(r, R - 1); }
+#pragma unroll
+            for (int q = 0; q < ORB_MAX_ROOTS; q++) {
+                const unsigned long long m = __ballot(r == q);
+                if (r == q) kb[1][run[q] + __popcll(m & lanemask_lt())] = key;
+                run[q] += __popcll(m);
+            }
+        }
+    }
+    if (lane == 0) {
+        int p = 0;
+#pragma unroll
+        for (int r = 0; r < ORB_MAX_ROOTS; r++) {
+            if (r >= R || rcount[r] == 0) continue;
+            cur.x0[p] = (short)(int)(L.hx * (float)r);
+            cur.x1[p] = (short)(int)(L.hx * (float)(r + 1));
+            cur.y0[p] = 0; cur.y1[p] = (short)L.bh;
+            cur.first[p] = rbase[r]; cur.count[p] = rcount[r]; cur.buf[p] = 1;
+            p++;
+        }
+        *shared_len = p;
+    }
+    wave_sync_mem();
+    int len = *shared_len;
+
+    // ---- refinement passes
+    bool finish = false, careful = false;
+    int guard = 0;
+    while (!finish) {
+        if (++guard > 512) { if (lane == 0) atomicOr(status, 2); break; }
+        const int prev = len;
+        // (1) child key counts of every node holding more than one key
+        for (int p = 0; p < len; p++) {
+            const int cnt = cur.count[p];
+            if (cnt <= 1) continue;
+            const int sx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;       // x0 + ceil(w/2)  (:652)
+            const int sy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
+            const unsigned* src = kb[cur.buf[p]] + cur.first[p];
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int base = 0; base < cnt; base += 64) {
+                const int i = base + lane;
+                int q = -1;
+                if (i < cnt) {
+                    const unsigned key = src[i];
+                    q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);  // n1,n2,n3,n4 (:684-694)
+                }
+                c0 += __popcll(__ballot(q == 0)); c1 += __popcll(__ballot(q == 1));
+                c2 += __popcll(__ballot(q == 2)); c3 += __popcll(__ballot(q == 3));
+            }
+            if (lane == 0) { cc[4 * p] = c0; cc[4 * p + 1] = c1; cc[4 * p + 2] = c2; cc[4 * p + 3] = c3; }
+        }
+        wave_sync_mem();
+        // (2) the divided nodes in processing order: ord[k] = list position of the k-th
+        int nd = 0;
+        if (!careful) {
+            for (int base = 0; base < len; base += 64) {
+                const int p = base + lane;
+                const bool dv = p < len && cur.count[p] > 1;
+                const unsigned long long m = __ballot(dv);
+                if (dv) ord[nd + __popcll(m & lanemask_lt())] = p;
+                nd += __popcll(m);
+            }
+        } else {
+            // descending (count, creation): new children sit at the list front in reverse creation
+            // order, so "created later" == smaller position
+            int m_c = 0;
+            for (int base = 0; base < len; base += 64) {
+                const int p = base + lane;
+                const int myc = p < len ? cur.count[p] : 0;
+                const bool cand = myc > 1;
+                if (cand) {
+                    int rank = 0;
+                    for (int q = 0; q < len; q++) {
+                        const int cq = cur.count[q];
+                        rank += (cq > 1 && (cq > myc || (cq == myc && q < p))) ? 1 : 0;
+                    }
+                    ord[rank] = p;
+                    gain[rank] = oct_nonempty(cc, p) - 1;
+                }
+                m_c += __popcll(__ballot(cand));
+            }
+            wave_sync_mem();
+            // stop after the first node that brings the list to N (:898); otherwise divide all
+            int run = len, K = m_c - 1;
+            bool found = false;
+            for (int base = 0; base < m_c && !found; base += 64) {
+                const int k = base + lane;
+                const int gn = k < m_c ? gain[k] : 0;
+                const int incl = wave_incl_scan(gn);
+                const unsigned long long hit = __ballot(k < m_c && run + incl >= N);
+                if (hit != 0ull) { K = base + __ffsll((long long)hit) - 1; found = true; }
+                run += __shfl(incl, 63, 64);
+            }
+            nd = m_c > 0 ? K + 1 : 0;
+        }
+        wave_sync_mem();
+        // (3) creation index of each divided node's first child; T = children created in this pass
+        int T = 0;
+        for (int base = 0; base < nd; base += 64) {
+            const int k = base + lane;
+            const int ne = k < nd ? oct_nonempty(cc, ord[k]) : 0;
+            const int incl = wave_incl_scan(ne);
+            if (k < nd) cbase[k] = T + incl - ne;
+            T += __shfl(incl, 63, 64);
+        }
+        for (int base = 0; base < len; base += 64) { const int p = base + lane; if (p < len) mark[p] = 0; }
+        wave_sync_mem();
+        for (int base = 0; base < nd; base += 64) { const int k = base + lane; if (k < nd) mark[ord[k]] = k + 1; }
+        wave_sync_mem();
+        // (4) survivors keep their order behind the new children
+        int nsurv = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int p = base + lane;
+            const bool sv = p < len && mark[p] == 0;
+            const unsigned long long m = __ballot(sv);
+            if (sv) {
+                const int dest = T + nsurv + __popcll(m & lanemask_lt());
+                if (dest < cap) {
+                    nxt.x0[dest] = cur.x0[p]; nxt.y0[dest] = cur.y0[p]; nxt.x1[dest] = cur.x1[p]; nxt.y1[dest] = cur.y1[p];
+                    nxt.first[dest] = cur.first[p]; nxt.count[dest] = cur.count[p]; nxt.buf[dest] = cur.buf[p];
+                }
+            }
+            nsurv += __popcll(m);
+        }
+        const int newlen = T + nsurv;
+        if (newlen > cap) { if (lane == 0) atomicOr(status, 4); break; }
+        // (5) children, pushed to the front one by one: creation index c -> position T-1-c
+        int newExpand = 0;
+        for (int base = 0; base < nd; base += 64) {
+            const int k = base + lane;
+            int gt1 = 0;
+            if (k < nd) {
+                const int p = ord[k];
+                const int px0 = cur.x0[p], py0 = cur.y0[p], px1 = cur.x1[p], py1 = cur.y1[p];
+                const int sx = px0 + (px1 - px0 + 1) / 2, sy = py0 + (py1 - py0 + 1) / 2;
+                int ci = cbase[k];
+                int kf = cur.first[p];
+                const int pb = cur.buf[p] ^ 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int c = cc[4 * p + q];
+                    if (c > 0) {
+                        const int dest = T - 1 - ci;
+                        nxt.x0[dest] = (short)((q & 1) ? sx : px0);
+                        nxt.x1[dest] = (short)((q & 1) ? px1 : sx);
+                        nxt.y0[dest] = (short)((q & 2) ? sy : py0);
+                        nxt.y1[dest] = (short)((q & 2) ? py1 : sy);
+                        nxt.first[dest] = kf; nxt.count[dest] = c; nxt.buf[dest] = (uint8_t)pb;
+                        ci++;
+                        gt1 += (c > 1);
+                    }
+                    kf += c;
+                }
+            }
+            newExpand += wave_sum(gt1);
+        }
+        // (6) stable 4-way partition of each divided node's keys into the other scratch buffer
+        for (int k = 0; k < nd; k++) {
+            const int p = ord[k];
+            const int cnt = cur.count[p];
+            const int sx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;
+            const int sy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
+            const int pb = cur.buf[p];
+            const unsigned* src = kb[pb] + cur.first[p];
+            unsigned* dst = kb[pb ^ 1] + cur.first[p];
+            int r0 = 0, r1 = cc[4 * p], r2 = r1 + cc[4 * p + 1], r3 = r2 + cc[4 * p + 2];
+            const unsigned long long lt = lanemask_lt();
+            for (int base = 0; base < cnt; base += 64) {
+                const int i = base + lane;
+                int q = -1; unsigned key = 0;
+                if (i < cnt) {
+                    key = src[i];
+                    q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
+                }
+                const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1);
+                const unsigned long long m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+                if (q == 0) dst[r0 + __popcll(m0 & lt)] = key;
+                else if (q == 1) dst[r1 + __popcll(m1 & lt)] = key;
+                else if (q == 2) dst[r2 + __popcll(m2 & lt)] = key;
+                else if (q == 3) dst[r3 + __popcll(m3 & lt)] = key;
+                r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+            }
+        }
+        wave_sync_mem();
+        { OctNodes t = cur; cur = nxt; nxt = t; }
+        len = newlen;
+        // (7) loop control (:837-905)
+        if (len >= N || len == prev) finish = true;
+        else if (!careful && len + 3 * newExpand > N) careful = true;
+    }
+
+    // ---- keep the best response of every node, first key wins ties (:912-928); order = list order
+    unsigned* o = out + (long long)f * g->out_per_frame + L.out_first;
+    for (int base = 0; base < len; base += 64) {
+        const int p = base + lane;
+        if (p < len && p < L.out_cap) {
+            const unsigned* src = kb[cur.buf[p]] + cur.first[p];
+            const int cnt = cur.count[p];
+            unsigned best = src[0];
+            for (int k = 1; k < cnt; k++) {
+                const unsigned key = src[k];
+                if ((key >> 24) > (best >> 24)) best = key;
+            }
+            o[p] = best;
+        }
+    }
+    if (lane == 0) *ocount = min(len, L.out_cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_orient_desc: one wave per selected keypoint.
+//   IC_Angle (ORBextractor.cpp:68-95) on the un-blurred level, cv::fastAtan2;
+//   GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101 (:1259; integer taps {18,34,49,55,49,34,18},
+//   SURVEY.md 12.6) evaluated only on the 37x37 neighbourhood the pattern can reach -- the sum
+//   sum_ij q_i q_j src is exact in integers, so it equals the reference's full-image separable
+//   blur bit for bit and the blurred pyramid is never written to HBM;
+//   computeOrbDescriptor (:100-316): bit k = I(p_2k) < I(p_2k+1) with the pattern rotated by the angle.
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.2204460492503131e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.2204460492503131e-16f);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+#define OD_SRC_PITCH 44
+#define OD_H_PITCH 38
+#define OD_B_PITCH 40
+#define OD_WAVE_LDS (ORB_PATCH_D * OD_SRC_PITCH + ORB_PATCH_D * OD_H_PITCH * 2 + ORB_BLUR_D * OD_B_PITCH + 12)
+
+__constant__ signed char c_pattern[1024];
+
+__global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom* __restrict__ g, const unsigned* __restrict__ sel,
+                                                     const int* __restrict__ sel_count,
+                                                     ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                     int* __restrict__ counts, int max_per_image, int* __restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][(OD_WAVE_LDS + 15) & ~15];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int slot = blockIdx.x * 4 + wv, f = blockIdx.y;
+    if (slot >= g->out_per_frame) return;
+    // slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
+    int level = 0;
+    for (int l = 1; l < g->nlevels; l++) if (slot >= g->lv[l].out_first) level = l;
+    const OrbLevel& L = g->lv[level];
+    const int k = slot - L.out_first;
+    const int* sc = sel_count + (long long)f * g->nlevels;
+    int row = k, tot = 0;
+    for (int l = 0; l < g->nlevels; l++) { const int c = sc[l]; if (l < level) row += c; tot += c; }
+    if (slot == 0 && lane == 0) {
+        counts[f] = min(tot, max_per_image);
+        if (tot > max_per_image) atomicOr(status, 8);
+    }
+    if (k >= sc[level] || row >= max_per_image) return;
+
+    const unsigned key = sel[(long long)f * g->out_per_frame + slot];
+    const int cx = (int)(key & 0xFFFu) + ORB_BORDER, cy = (int)((key >> 12) & 0xFFFu) + ORB_BORDER;   // :1012-1013
+    const int score = (int)(key >> 24);
+
+    uint8_t* src = lds[wv];
+    unsigned short* hb = reinterpret_cast<unsigned short*>(src + ORB_PATCH_D * OD_SRC_PITCH);
+    uint8_t* bl = reinterpret_cast<uint8_t*>(hb + ORB_PATCH_D * OD_H_PITCH);
+    const uint8_t* img = L.img + (long long)f * L.plane;
+    for (int i = lane; i < ORB_PATCH_D * ORB_PATCH_D; i += 64) {
+        const int py = i / ORB_PATCH_D, px = i - py * ORB_PATCH_D;
+        const int gy = reflect101(cy + py - ORB_PATCH_R, L.h), gx = reflect101(cx + px - ORB_PATCH_R, L.w);
+        src[py * OD_SRC_PITCH + px] = img[(long long)gy * L.pitch + gx];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- IC_Angle: integer moments over the radius-15 disc
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int vv = i / 31 - 15, uu = i - (i / 31) * 31 - 15;
+        const int lim = g->umax[vv < 0 ? -vv : vv];
+        if (uu >= -lim && uu <= lim) {
+            const int I = src[(ORB_PATCH_R + vv) * OD_SRC_PITCH + ORB_PATCH_R + uu];
+            m10 += uu * I; m01 += vv * I;
+        }
+    }
+    m10 = wave_sum(m10); m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- horizontal 7 taps: rows 0..42, output columns 3..39 of the patch -> hb[row][0..36]
+    for (int i = lane; i < ORB_PATCH_D * ORB_BLUR_D; i += 64) {
+        const int py = i / ORB_BLUR_D, ox = i - py * ORB_BLUR_D;
+        const uint8_t* s = src + py * OD_SRC_PITCH + ox;
+        const int v = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 49 * (s[2] + s[4]) + 55 * s[3];
+        hb[py * OD_H_PITCH + ox] = (unsigned short)v;       // <= 255*257 = 65535
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- vertical 7 taps + single rounding: blurred 37x37 neighbourhood
+    for (int i = lane; i < ORB_BLUR_D * ORB_BLUR_D; i += 64) {
+        const int oy = i / ORB_BLUR_D, ox = i - oy * ORB_BLUR_D;
+        const unsigned short* h = hb + oy * OD_H_PITCH + ox;
+        int v = 18 * (h[0] + h[6 * OD_H_PITCH]) + 34 * (h[OD_H_PITCH] + h[5 * OD_H_PITCH]) +
+                49 * (h[2 * OD_H_PITCH] + h[4 * OD_H_PITCH]) + 55 * h[3 * OD_H_PITCH];
+        v = (v + 32768) >> 16;
+        bl[oy * OD_B_PITCH + ox] = (uint8_t)min(v, 255);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- steered BRIEF: lane L evaluates pairs L, 64+L, 128+L, 192+L; a ballot is 8 descriptor bytes
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    ccm_sincosf(angle * factorPI, &b, &a);
+    uint8_t* drow = desc + ((long long)f * max_per_image + row) * 32;
+    const uint8_t* ctr = bl + 18 * OD_B_PITCH + 18;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const signed char* pp = c_pattern + 4 * (r * 64 + lane);
+        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const int t0 = ctr[__float2int_rn(x0 * b + y0 * a) * OD_B_PITCH + __float2int_rn(x0 * a - y0 * b)];
+        const int t1 = ctr[__float2int_rn(x1 * b + y1 * a) * OD_B_PITCH + __float2int_rn(x1 * a - y1 * b)];
+        const unsigned long long bits = __ballot(t0 < t1);
+        if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + 8 * r) = bits;
+    }
+    if (lane == 0) {
+        ccm_keypoint kp;
+        kp.x = (float)cx; kp.y = (float)cy;
+        if (level != 0) { kp.x *= L.scale; kp.y *= L.scale; }              // :1268-1274
+        kp.size = L.kp_size; kp.angle = angle; kp.response = (float)score;
+        kp.octave = level; kp.class_id = -1;
+        kps[(long long)f * max_per_image + row] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (called from orb_host.cpp)
+extern "C" hipError_t orb_upload_pattern()
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ccm_orb_pattern, 1024);
+}
+
+size_t orb_octree_lds_bytes(int list_cap) { return (size_t)list_cap * OCT_NODE_LDS + 64; }
+
+void orb_launch_resize(hipStream_t s, const OrbGeom* g_dev, int level, int dw, int dh, int nframes)
+{
+    dim3 grid((dw + 255) / 256, (dh + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, g_dev, level);
+}
+void orb_launch_score(hipStream_t s, const OrbGeom* g_dev, int ntiles, int nframes)
+{
+    hipLaunchKernelGGL(k_fast_score, dim3(ntiles, nframes), dim3(256), 0, s, g_dev);
+}
+void orb_launch_nms(hipStream_t s, const OrbGeom* g_dev, const OrbCell* cells, int ncells, int nframes,
+                    unsigned* slots, int* cell_count)
+{
+    hipLaunchKernelGGL(k_cell_nms, dim3((ncells + 3) / 4, nframes), dim3(256), 0, s, g_dev, cells, slots, cell_count);
+}
+void orb_launch_octree(hipStream_t s, const OrbGeom* g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,
+                       const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
+                       unsigned* out, int* out_count, int* status)
+{
+    hipLaunchKernelGGL(k_octree, dim3(nlevels, nframes), dim3(64), orb_octree_lds_bytes(list_cap), s,
+                       g_dev, cells, slots, cell_count, keysA, keysB, out, out_count, status);
+}
+void orb_launch_orient_desc(hipStream_t s, const OrbGeom* g_dev, int out_per_frame, int nframes, const unsigned* sel,
+                            const int* sel_count, ccm_keypoint* kps, uint8_t* desc, int* counts, int max_per_image,
+                            int* status)
+{
+    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + 3) / 4, nframes), dim3(256), 0, s,
+                       g_dev, sel, sel_count, kps, desc, counts, max_per_image, status);
+}

@@ -1,1 +1,325 @@
+// ba_kernels.hip -- CDNA4 kernels of the 6-DoF pose / 3-DoF point reprojection bundle adjustment
+// (what src/Optimizer.cpp hands to g2o's BlockSolver_6_3 + Levenberg).  All arithmetic is float64.
+//
+// Edge storage is sorted by (landmark, pose): a landmark's observations are contiguous, which is the
+// order BlockSolver::solve walks them in (block_solver.hpp:381-432).
+//   k_ba_pose_rt      quaternion+t -> R|t per pose
+//   k_ba_errors       computeActiveErrors + activeRobustChi2            (sparse_optimizer.cpp:61-114)
+//   k_ba_lin_landmark linearizeOplus + constructQuadraticForm, landmark side: Hll, b_l, Hpl per edge
+//   k_ba_lin_pose     the same, pose side: Hpp, b_p (one wave per free pose, fixed summation order)
+//   k_ba_schur        per landmark: Dinv, Hschur -= Hpl Dinv Hpl^T, bschur -= Hpl Dinv b_l
+//   k_ba_backsub      x_l = Dinv (b_l - Hpl^T x_p)                        (block_solver.hpp:461-481)
+//   k_ba_update       oplus on poses (exp map) and points                 (sparse_optimizer.cpp:422-435)
 #include <hip/hip_runtime.h>
+#include <cstdint>
+#include "ba_math.h"
+#include "ba_types.h"
+
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_ba_pose_rt(BaDev D)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= D.P) return;
+    double R[9];
+    ba_quat_to_R(D.poses + 7 * (long long)p, R);
+    double* o = D.Rt + 12 * (long long)p;
+    for (int i = 0; i < 9; i++) o[i] = R[i];
+    o[9] = D.poses[7 * (long long)p + 4]; o[10] = D.poses[7 * (long long)p + 5]; o[11] = D.poses[7 * (long long)p + 6];
+}
+
+// One thread per edge; block partial sums of rho(chi2) in a fixed tree -> partial[blockIdx.x]
+__global__ __launch_bounds__(256) void k_ba_errors(BaDev D, double huber_delta, double* __restrict__ partial)
+{
+    __shared__ double red[4];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double r = 0;
+    if (e < D.E && D.active[e]) {
+        const int pi = D.edge_pose[e], li = D.edge_point[e];
+        double er[2];
+        ba_edge_eval(D.Rt + 12 * (long long)pi, D.intr + 4 * (long long)pi, D.points + 3 * (long long)li,
+                     D.obs + 2 * (long long)e, er, nullptr, nullptr, nullptr);
+        D.err[2 * (long long)e] = er[0]; D.err[2 * (long long)e + 1] = er[1];
+        const double c2 = D.info[e] * (er[0] * er[0] + er[1] * er[1]);
+        if (huber_delta > 0) { double r1; ba_huber(c2, huber_delta, &r, &r1); }
+        else r = c2;
+    }
+    r = wave_sum_d(r);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Sum n doubles with one block in a fixed order; optional max instead of sum.  out[0] = result.
+__global__ __launch_bounds__(256) void k_ba_reduce(const double* __restrict__ in, int n, double* __restrict__ out, int take_max)
+{
+    __shared__ double red[256];
+    double acc = take_max ? 0.0 : 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc = take_max ? fmax(acc, fabs(in[i])) : acc + in[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = take_max ? fmax(red[threadIdx.x], red[threadIdx.x + s]) : red[threadIdx.x] + red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// One thread per landmark: accumulate Hll (full 3x3) and b_l over its edges, store Hpl = w B^T A per edge.
+__global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_delta)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= D.L) return;
+    double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, b[3] = { 0, 0, 0 };
+    const double* pt = D.points + 3 * (long long)l;
+    const double p3[3] = { pt[0], pt[1], pt[2] };
+    for (int e = D.pt_first[l]; e < D.pt_first[l + 1]; e++) {
+        double* Hx = D.Hpl + 18 * (long long)e;
+        if (!D.active[e]) { for (int i = 0; i < 18; i++) Hx[i] = 0; continue; }
+        const int pi = D.edge_pose[e];
+        double er[2], A[6], B[12];
+        ba_edge_eval(D.Rt + 12 * (long long)pi, D.intr + 4 * (long long)pi, p3, D.obs + 2 * (long long)e, er, A, B, nullptr);
+        const double om = D.info[e];
+        double r0, r1 = 1.;
+        if (huber_delta > 0) ba_huber(om * (er[0] * er[0] + er[1] * er[1]), huber_delta, &r0, &r1);
+        const double w = r1 * om;
+        const double g0 = -om * er[0] * r1, g1 = -om * er[1] * r1;
+        for (int i = 0; i < 3; i++) {
+            b[i] += A[i] * g0 + A[3 + i] * g1;
+            for (int j = 0; j < 3; j++) H[i * 3 + j] += w * (A[i] * A[j] + A[3 + i] * A[3 + j]);
+        }
+        const bool fr = D.free_of[pi] >= 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 3; j++) Hx[i * 3 + j] = fr ? w * (B[i] * A[j] + B[6 + i] * A[3 + j]) : 0.0;
+    }
+    for (int i = 0; i < 9; i++) D.Hll[9 * (long long)l + i] = H[i];
+    for (int i = 0; i < 3; i++) D.bl[3 * (long long)l + i] = b[i];
+}
+
+// One wave per free pose: lanes stride the pose's edge list, then a fixed butterfly reduction.
+__global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D, double huber_delta)
+{
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (f >= D.nfree) return;
+    const int pi = D.pose_of_free[f];
+    double Rt[12], K[4];
+    for (int i = 0; i < 12; i++) Rt[i] = D.Rt[12 * (long long)pi + i];
+    for (int i = 0; i < 4; i++) K[i] = D.intr[4 * (long long)pi + i];
+    double H[21], b[6];
+    for (int i = 0; i < 21; i++) H[i] = 0;
+    for (int i = 0; i < 6; i++) b[i] = 0;
+    for (int k = D.pose_first[f] + lane; k < D.pose_first[f + 1]; k += 64) {
+        const int e = D.pose_edges[k];
+        if (!D.active[e]) continue;
+        double er[2], A[6], B[12];
+        ba_edge_eval(Rt, K, D.points + 3 * (long long)D.edge_point[e], D.obs + 2 * (long long)e, er, A, B, nullptr);
+        const double om = D.info[e];
+        double r0, r1 = 1.;
+        if (huber_delta > 0) ba_huber(om * (er[0] * er[0] + er[1] * er[1]), huber_delta, &r0, &r1);
+        const double w = r1 * om;
+        const double g0 = -om * er[0] * r1, g1 = -om * er[1] * r1;
+        int m = 0;
+        for (int i = 0; i < 6; i++) {
+            b[i] += B[i] * g0 + B[6 + i] * g1;
+            for (int j = i; j < 6; j++) H[m++] += w * (B[i] * B[j] + B[6 + i] * B[6 + j]);
+        }
+    }
+    for (int i = 0; i < 21; i++) H[i] = wave_sum_d(H[i]);
+    for (int i = 0; i < 6; i++) b[i] = wave_sum_d(b[i]);
+    if (lane == 0) {
+        double* o = D.Hpp + 36 * (long long)f;
+        int m = 0;
+        for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) { o[i * 6 + j] = H[m]; o[j * 6 + i] = H[m]; m++; }
+        for (int i = 0; i < 6; i++) D.bp[6 * (long long)f + i] = b[i];
+    }
+}
+
+// Hs (n x n row-major, upper block triangle used) = blockdiag(Hpp) [+ lambda I], bs = bp.
+__global__ __launch_bounds__(256) void k_ba_init_reduced(BaDev D, double lambda_diag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;          // over nfree*36
+    if (i >= D.nfree * 36) return;
+    const int f = i / 36, r = (i % 36) / 6, c = i % 6;
+    const long long n = 6LL * D.nfree;
+    D.Hs[(6LL * f + r) * n + 6 * f + c] = D.Hpp[i] + (r == c ? lambda_diag : 0.0);
+    if (i < D.nfree * 6) D.bs[i] = D.bp[i];
+}
+__global__ __launch_bounds__(256) void k_ba_add_diag(double* Hs, long long n, double v)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i < n) Hs[i * n + i] += v;
+}
+
+// One thread per landmark: Schur complement contributions (block_solver.hpp:381-432) with lambda on
+// the landmark diagonal (setLambda :564-589).  f64 hardware atomics scatter into Hs / bs.
+__global__ __launch_bounds__(128) void k_ba_schur(BaDev D, double lambda)
+{
+    const int l = blockIdx.x * 128 + threadIdx.x;
+    if (l >= D.L) return;
+    double Dm[9], Di[9];
+    for (int i = 0; i < 9; i++) Dm[i] = D.Hll[9 * (long long)l + i];
+    Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+    ba_inv3(Dm, Di);
+    for (int i = 0; i < 9; i++) D.Dinv[9 * (long long)l + i] = Di[i];
+    const double b0 = D.bl[3 * (long long)l], b1 = D.bl[3 * (long long)l + 1], b2 = D.bl[3 * (long long)l + 2];
+    const double db0 = Di[0] * b0 + Di[1] * b1 + Di[2] * b2;
+    const double db1 = Di[3] * b0 + Di[4] * b1 + Di[5] * b2;
+    const double db2 = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
+    const long long n = 6LL * D.nfree;
+    const int e0 = D.pt_first[l], e1 = D.pt_first[l + 1];
+    for (int a = e0; a < e1; a++) {
+        const int f1 = D.free_of[D.edge_pose[a]];
+        if (f1 < 0 || !D.active[a]) continue;
+        const double* Bi = D.Hpl + 18 * (long long)a;
+        double BD[18];
+        for (int i = 0; i < 6; i++) {
+            const double x = Bi[i * 3], y = Bi[i * 3 + 1], z = Bi[i * 3 + 2];
+            BD[i * 3] = x * Di[0] + y * Di[3] + z * Di[6];
+            BD[i * 3 + 1] = x * Di[1] + y * Di[4] + z * Di[7];
+            BD[i * 3 + 2] = x * Di[2] + y * Di[5] + z * Di[8];
+            unsafeAtomicAdd(D.bs + 6 * f1 + i, -(x * db0 + y * db1 + z * db2));
+        }
+        for (int b = a; b < e1; b++) {
+            const int f2 = D.free_of[D.edge_pose[b]];
+            if (f2 < 0 || !D.active[b]) continue;
+            const double* Bj = D.Hpl + 18 * (long long)b;
+            double* dst = D.Hs + (6LL * f1) * n + 6 * f2;
+            for (int j = 0; j < 6; j++) {
+                const double x = Bj[j * 3], y = Bj[j * 3 + 1], z = Bj[j * 3 + 2];
+                for (int i = 0; i < 6; i++)
+                    unsafeAtomicAdd(dst + i * n + j, -(BD[i * 3] * x + BD[i * 3 + 1] * y + BD[i * 3 + 2] * z));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ba_backsub(BaDev D)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= D.L) return;
+    double c0 = D.bl[3 * (long long)l], c1 = D.bl[3 * (long long)l + 1], c2 = D.bl[3 * (long long)l + 2];
+    for (int e = D.pt_first[l]; e < D.pt_first[l + 1]; e++) {
+        const int f = D.free_of[D.edge_pose[e]];
+        if (f < 0 || !D.active[e]) continue;
+        const double* Bi = D.Hpl + 18 * (long long)e;
+        const double* xp = D.x + 6 * f;
+        for (int i = 0; i < 6; i++) { c0 -= Bi[i * 3] * xp[i]; c1 -= Bi[i * 3 + 1] * xp[i]; c2 -= Bi[i * 3 + 2] * xp[i]; }
+    }
+    const double* Di = D.Dinv + 9 * (long long)l;
+    double* xl = D.x + 6LL * D.nfree + 3 * (long long)l;
+    xl[0] = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
+    xl[1] = Di[3] * c0 + Di[4] * c1 + Di[5] * c2;
+    xl[2] = Di[6] * c0 + Di[7] * c1 + Di[8] * c2;
+}
+
+__global__ __launch_bounds__(256) void k_ba_update(BaDev D)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < D.nfree) {
+        const int p = D.pose_of_free[i];
+        double o[7];
+        ba_se3_exp_mul(D.x + 6 * i, D.poses + 7 * (long long)p, o);
+        for (int k = 0; k < 7; k++) D.poses[7 * (long long)p + k] = o[k];
+    }
+    if (i < D.L) for (int k = 0; k < 3; k++) D.points[3 * (long long)i + k] += D.x[6LL * D.nfree + 3 * (long long)i + k];
+}
+
+// computeScale partial (optimization_algorithm_levenberg.cpp:182-189):
+//   sum_poses x*b_p (+ lambda x^2 if add_pose_lambda) + sum_landmarks x*(lambda x + b_l) -> partial[block]
+__global__ __launch_bounds__(256) void k_ba_scale(BaDev D, double lambda, int add_pose_lambda, double* __restrict__ partial)
+{
+    __shared__ double red[4];
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    const long long np = 6LL * D.nfree, nx = np + 3LL * D.L;
+    double v = 0;
+    if (i < np) v = D.x[i] * ((add_pose_lambda ? lambda * D.x[i] : 0.0) + D.bp[i]);
+    else if (i < nx) v = D.x[i] * (lambda * D.x[i] + D.bl[i - np]);
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// max |diagonal| of Hll (local landmarks) and of Hpp -> partial arrays (computeLambdaInit :166-180)
+__global__ __launch_bounds__(256) void k_ba_diag(BaDev D, double* __restrict__ out_ll, double* __restrict__ out_pp_diag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < D.L) {
+        const double* H = D.Hll + 9 * (long long)i;
+        out_ll[i] = fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8])));
+    }
+    if (i < D.nfree * 6) out_pp_diag[i] = D.Hpp[36 * (long long)(i / 6) + 7 * (i % 6)];
+}
+
+// outlier test of src/Optimizer.cpp:556 / :582 from the LAST COMPUTED errors (g2o does not recompute
+// them after a rejected step or for level-1 edges) and the current depth.
+__global__ __launch_bounds__(256) void k_ba_outliers(BaDev D, double chi2_th, uint8_t* __restrict__ flag)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= D.E) return;
+    const int pi = D.edge_pose[e], li = D.edge_point[e];
+    const double* Rt = D.Rt + 12 * (long long)pi; const double* p = D.points + 3 * (long long)li;
+    const double z = Rt[6] * p[0] + Rt[7] * p[1] + Rt[8] * p[2] + Rt[11];
+    const double e0 = D.err[2 * (long long)e], e1 = D.err[2 * (long long)e + 1];
+    const double c2 = D.info[e] * (e0 * e0 + e1 * e1);
+    flag[e] = (c2 > chi2_th || !(z > 0.0)) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_ba_deactivate(BaDev D, const uint8_t* __restrict__ flag)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < D.E && flag[e]) D.active[e] = 0;
+}
+
+// ---- launchers
+static inline int nblk(long long n, int b) { return (int)((n + b - 1) / b); }
+void ba_launch_pose_rt(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_pose_rt, dim3(nblk(D.P, 256)), dim3(256), 0, s, D); }
+int ba_errors_blocks(const BaDev& D) { return nblk(D.E, 256); }
+void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial, double* out)
+{
+    const int nb = nblk(D.E, 256);
+    hipLaunchKernelGGL(k_ba_errors, dim3(nb), dim3(256), 0, s, D, hd, partial);
+    hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, partial, nb, out, 0);
+}
+void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
+{
+    hipLaunchKernelGGL(k_ba_lin_landmark, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);
+    if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
+}
+void ba_launch_init_reduced(hipStream_t s, const BaDev& D, double lambda_diag)
+{
+    if (D.nfree > 0) hipLaunchKernelGGL(k_ba_init_reduced, dim3(nblk(D.nfree * 36LL, 256)), dim3(256), 0, s, D, lambda_diag);
+}
+void ba_launch_add_diag(hipStream_t s, const BaDev& D, double v)
+{
+    if (D.nfree > 0) hipLaunchKernelGGL(k_ba_add_diag, dim3(nblk(6LL * D.nfree, 256)), dim3(256), 0, s, D.Hs, 6LL * D.nfree, v);
+}
+void ba_launch_schur(hipStream_t s, const BaDev& D, double lambda)
+{
+    hipLaunchKernelGGL(k_ba_schur, dim3(nblk(D.L, 128)), dim3(128), 0, s, D, lambda);
+}
+void ba_launch_backsub(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_backsub, dim3(nblk(D.L, 256)), dim3(256), 0, s, D); }
+void ba_launch_update(hipStream_t s, const BaDev& D)
+{
+    const int n = D.L > D.nfree ? D.L : D.nfree;
+    hipLaunchKernelGGL(k_ba_update, dim3(nblk(n, 256)), dim3(256), 0, s, D);
+}
+int ba_scale_blocks(const BaDev& D) { return nblk(6LL * D.nfree + 3LL * D.L, 256); }
+void ba_launch_scale(hipStream_t s, const BaDev& D, double lambda, int add_pose_lambda, double* partial, double* out)
+{
+    const int nb = ba_scale_blocks(D);
+    hipLaunchKernelGGL(k_ba_scale, dim3(nb), dim3(256), 0, s, D, lambda, add_pose_lambda, partial);
+    hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, partial, nb, out, 0);
+}
+void ba_launch_diag(hipStream_t s, const BaDev& D, double* tmp_ll, double* pp_diag, double* out_ll_max)
+{
+    const int n = D.L > D.nfree * 6 ? D.L : D.nfree * 6;
+    hipLaunchKernelGGL(k_ba_diag, dim3(nblk(n, 256)), dim3(256), 0, s, D, tmp_ll, pp_diag);
+    hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, tmp_ll, D.L, out_ll_max, 1);
+}
+void ba_launch_outliers(hipStream_t s, const BaDev& D, double th, uint8_t* flag) { hipLaunchKernelGGL(k_ba_outliers, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, th, flag); }
+void ba_launch_deactivate(hipStream_t s, const BaDev& D, const uint8_t* flag) { hipLaunchKernelGGL(k_ba_deactivate, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, flag); }

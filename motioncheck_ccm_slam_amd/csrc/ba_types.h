@@ -1,0 +1,29 @@
+// ba_types.h -- device view of one bundle-adjustment problem (all pointers are device memory).
+#pragma once
+#include <cstdint>
+
+struct BaDev {
+    int P, L, E, nfree;            // poses (all), landmarks (this rank's), edges (this rank's), free poses
+    double* poses;                 // [P][7] qx qy qz qw tx ty tz
+    double* Rt;                    // [P][12] R row-major, then t
+    const double* intr;            // [P][4] fx fy cx cy
+    const int* free_of;            // [P] free index or -1
+    const int* pose_of_free;       // [nfree]
+    double* points;                // [L][3]
+    // edges sorted by (landmark, pose)
+    const int* edge_pose; const int* edge_point;
+    const double* obs;             // [E][2]
+    const double* info;            // [E]
+    uint8_t* active;               // [E] level 0
+    double* err;                   // [E][2] last computed error
+    const int* pt_first;           // [L+1] CSR landmark -> edges
+    const int* pose_first;         // [nfree+1] CSR free pose -> pose_edges
+    const int* pose_edges;
+    // system
+    double* Hpp; double* bp;       // [nfree][36], [nfree][6]
+    double* Hll; double* bl;       // [L][9], [L][3]
+    double* Hpl;                   // [E][18] 6x3 row-major
+    double* Dinv;                  // [L][9]
+    double* Hs; double* bs;        // (6 nfree)^2 row-major, upper block triangle; 6 nfree
+    double* x;                     // [6 nfree + 3 L]
+};

@@ -1,0 +1,92 @@
+"""Host-side mirror of `cslam::Optimizer` (include/cslam/Optimizer.h:84-97) over the C ABI.
+
+The reference's entry points take Map / KeyFrame / MapPoint objects and build a g2o graph
+(src/Optimizer.cpp:48-164, 406-530, 676-791).  Here the graph is passed as arrays -- exactly what
+those functions extract: SE3Quat poses of the keyframes, fixed flags, intrinsics, world points,
+one edge per observation with its pixel measurement and invSigma2 -- and the results come back
+where the reference writes them (poses / points), plus the outlier edges that
+LocalBundleAdjustmentClient erases (src/Optimizer.cpp:570-602).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BaOptions, BaProblem, BaResult
+
+TH_HUBER_2D_GLOBAL = float(np.sqrt(5.99))    # src/Optimizer.cpp:81, :712
+TH_HUBER_2D_LOCAL = float(np.sqrt(5.991))    # src/Optimizer.cpp:468
+CHI2_MONO = 5.991                            # src/Optimizer.cpp:556, :582
+
+
+def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None):
+    lib = _lib.load()
+    keep = dict(
+        poses=np.ascontiguousarray(graph["poses"], "f8").copy(), fixed=np.ascontiguousarray(graph["fixed"], np.uint8),
+        intr=np.ascontiguousarray(graph["intr"], "f8"), points=np.ascontiguousarray(graph["points"], "f8").copy(),
+        edge_pose=np.ascontiguousarray(graph["edge_pose"], "i4"), edge_point=np.ascontiguousarray(graph["edge_point"], "i4"),
+        obs=np.ascontiguousarray(graph["obs"], "f8"), info=np.ascontiguousarray(graph["info"], "f8"))
+    p = _lib.ptr
+    pb = BaProblem(len(keep["poses"]), p(keep["poses"]), p(keep["fixed"]), p(keep["intr"]),
+                   len(keep["points"]), p(keep["points"]), len(keep["edge_pose"]),
+                   p(keep["edge_pose"]), p(keep["edge_point"]), p(keep["obs"]), p(keep["info"]))
+    outl = np.zeros(max(len(keep["edge_pose"]), 1), np.uint8)
+    flag = None if stop_flag is None else np.ascontiguousarray(stop_flag, np.uint8)
+    opt = BaOptions(int(iterations), float(huber), int(iterations2), CHI2_MONO, p(flag))
+    res = BaResult()
+    res.edge_outlier = p(outl)
+    ctx.check(lib.ccm_ba_solve(ctx.handle, C.byref(pb), C.byref(opt), C.byref(res)))
+    return dict(poses=keep["poses"], points=keep["points"], outlier=outl[:len(keep["edge_pose"])],
+                iterations_done=res.iterations_done, trials=res.trials, chi2_initial=res.chi2_initial,
+                chi2_final=res.chi2_final, lambda_final=res.lambda_final, stopped=bool(res.stopped),
+                t_linearize=res.t_linearize, t_schur=res.t_schur, t_solve=res.t_solve, t_update=res.t_update)
+
+
+class Optimizer:
+    """Static-method style like the reference; `ctx` selects the GPU context (default: device 0)."""
+
+    @staticmethod
+    def BundleAdjustmentClient(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None):
+        ctx = ctx or _lib.default_context(0)
+        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag)
+
+    GlobalBundleAdjustemntClient = BundleAdjustmentClient      # [sic] the reference's spelling, Optimizer.h:86
+
+    @staticmethod
+    def LocalBundleAdjustmentClient(graph, pbStopFlag=None, ctx=None):
+        """5 robust iterations, outlier relabelling, 10 more without kernels (src/Optimizer.cpp:536-568)."""
+        ctx = ctx or _lib.default_context(0)
+        return _solve(ctx, graph, 5, TH_HUBER_2D_LOCAL, 10, pbStopFlag)
+
+    @staticmethod
+    def MapFusionGBA(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None):
+        ctx = ctx or _lib.default_context(0)
+        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag)
+
+
+def pose_from_mat4f(T: np.ndarray) -> np.ndarray:
+    T = np.ascontiguousarray(T, np.float32); out = np.zeros(7)
+    _lib.load().ccm_pose_from_mat4f(_lib.ptr(T), _lib.ptr(out))
+    return out
+
+
+def pose_to_mat4f(pose: np.ndarray) -> np.ndarray:
+    pose = np.ascontiguousarray(pose, np.float64); out = np.zeros((4, 4), np.float32)
+    _lib.load().ccm_pose_to_mat4f(_lib.ptr(pose), _lib.ptr(out))
+    return out
+
+
+def pose_delta(p_a: np.ndarray, p_b: np.ndarray) -> np.ndarray:
+    """|log(T_a T_b^-1)| per pose as a 6-vector magnitude bound: max(|rotation vector|, |translation diff|)."""
+    def rot(q):
+        x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+        return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                         np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                         np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+    Ra, Rb = rot(p_a[:, :4]), rot(p_b[:, :4])
+    dR = np.einsum("nij,nkj->nik", Ra, Rb)
+    ang = np.arccos(np.clip((np.trace(dR, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    dt = np.linalg.norm(p_a[:, 4:] - np.einsum("nij,nj->ni", dR, p_b[:, 4:]), axis=1)
+    return np.maximum(ang, dt)

@@ -87,6 +87,7 @@ def pose_delta(p_a: np.ndarray, p_b: np.ndarray) -> np.ndarray:
                          np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
     Ra, Rb = rot(p_a[:, :4]), rot(p_b[:, :4])
     dR = np.einsum("nij,nkj->nik", Ra, Rb)
-    ang = np.arccos(np.clip((np.trace(dR, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    v = np.stack([dR[:, 2, 1] - dR[:, 1, 2], dR[:, 0, 2] - dR[:, 2, 0], dR[:, 1, 0] - dR[:, 0, 1]], 1)
+    ang = np.arctan2(0.5 * np.linalg.norm(v, axis=1), (np.trace(dR, axis1=1, axis2=2) - 1) / 2)   # exact near 0
     dt = np.linalg.norm(p_a[:, 4:] - np.einsum("nij,nj->ni", dR, p_b[:, 4:]), axis=1)
     return np.maximum(ang, dt)

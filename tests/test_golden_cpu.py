@@ -1,0 +1,38 @@
+"""The oracle still reproduces the committed fixtures (tests/golden/, made by tools/make_golden.py)."""
+import hashlib
+import os
+
+import numpy as np
+
+from motioncheck_ccm_slam_amd import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_orb_frame0_fixture(oracle):
+    z = np.load(os.path.join(G, "orb_frame0.npz"))
+    r = oracle.orb_extract(oracle.default_params(), synth.frame(0), cand_level=0, want_levels=True)
+    assert (r["kps"] == z["kps"]).all() and (r["desc"] == z["desc"]).all()
+    assert (r["cand_xy"] == z["cand0_xy"]).all() and (r["cand_score"] == z["cand0_score"]).all()
+    assert [hashlib.sha256(l.tobytes()).hexdigest() for l in r["levels"]] == z["level_sha"].tolist()
+
+
+def test_orb_small_fixture(oracle):
+    z = np.load(os.path.join(G, "orb_small.npz"))
+    r = oracle.orb_extract(oracle.default_params(300, 1.2, 4, 20, 7), synth.frame(3, 200, 160))
+    assert (r["kps"] == z["kps"]).all() and (r["desc"] == z["desc"]).all()
+
+
+def test_match_fixture(oracle):
+    z = np.load(os.path.join(G, "match_pair0.npz"))
+    a, b = synth.descriptor_pair(0)
+    bi, bd, sd = oracle.hamming_match(a, b)
+    assert (bi == z["best_idx"]).all() and (bd == z["best_dist"]).all() and (sd == z["second_dist"]).all()
+
+
+def test_ba_fixture(oracle):
+    z = np.load(os.path.join(G, "ba_local.npz"))
+    res = oracle.ba_solve(synth.local_ba_graph(), 5, np.sqrt(5.991), 10)
+    assert np.abs(res["poses"] - z["poses"]).max() < 1e-12
+    assert np.allclose([res["chi2_initial"], res["chi2_final"]], z["chi2"], rtol=1e-12)
+    assert (np.flatnonzero(res["outlier"]) == z["outliers"]).all()

@@ -1,0 +1,104 @@
+"""HIP Hamming matcher vs the CPU oracle through the C ABI (BASELINE config 3) and SearchByBoW."""
+import os
+
+import numpy as np
+import pytest
+
+from motioncheck_ccm_slam_amd import synth
+from motioncheck_ccm_slam_amd.matcher import ORBmatcher
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_pairs_match_oracle_and_fixture(ctx, oracle):
+    m = ORBmatcher(0.7, ctx=ctx)
+    q, t = synth.descriptor_pairs(0, 8)
+    bi, bd, sd = m.BruteForce(q, t)
+    for p in range(8):
+        rbi, rbd, rsd = oracle.hamming_match(q[p], t[p])
+        assert (bi[p] == rbi).all() and (bd[p] == rbd).all() and (sd[p] == rsd).all()
+    z = np.load(os.path.join(G, "match_pair0.npz"))
+    assert (bi[0] == z["best_idx"]).all() and (bd[0] == z["best_dist"]).all() and (sd[0] == z["second_dist"]).all()
+    # ratio test of the callers
+    ok = m.RatioTest(bd[0], sd[0])
+    assert ok.sum() > 600 and ((bd[0] <= 50) | ~ok).all()
+
+
+def test_ties_pick_lowest_index(ctx, oracle):
+    m = ORBmatcher(ctx=ctx)
+    rng = np.random.default_rng(1)
+    t = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    t[200] = t[17]; t[250] = t[17]                # duplicates: the first index must win, second == best
+    q = t[[17, 5, 250]].copy()
+    q[1, 0] ^= 1
+    bi, bd, sd = m.BruteForce(q, t)
+    rbi, rbd, rsd = oracle.hamming_match(q, t)
+    assert (bi[0] == rbi).all() and (bd[0] == rbd).all() and (sd[0] == rsd).all()
+    assert bi[0, 0] == 17 and bd[0, 0] == 0 and sd[0, 0] == 0
+
+
+def test_ragged_empty_and_tiled(ctx, oracle):
+    m = ORBmatcher(ctx=ctx)
+    rng = np.random.default_rng(2)
+    q = rng.integers(0, 256, (3, 1300, 32), dtype=np.uint8)        # > 1024 queries: two query passes
+    t = rng.integers(0, 256, (3, 2500, 32), dtype=np.uint8)        # > 1024 train rows: three LDS tiles
+    nq_n = np.array([1300, 7, 0]); nt_n = np.array([2500, 1025, 300])
+    bi, bd, sd = m.BruteForce(q, t, nq_n, nt_n)
+    for p in range(3):
+        rbi, rbd, rsd = oracle.hamming_match(q[p, :nq_n[p]], t[p, :nt_n[p]])
+        assert (bi[p, :nq_n[p]] == rbi).all() and (bd[p, :nq_n[p]] == rbd).all() and (sd[p, :nq_n[p]] == rsd).all()
+        assert (bi[p, nq_n[p]:] == -1).all() and (bd[p, nq_n[p]:] == 256).all()
+    bi, bd, sd = m.BruteForce(q[:1, :10], t[:1, :0])               # no train rows at all
+    assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+    allz = np.zeros((1, 4, 32), np.uint8); allo = np.full((1, 4, 32), 255, np.uint8)
+    bi, bd, sd = m.BruteForce(allz, allo)                          # distance 256 is never a match (strict <)
+    assert (bi == -1).all() and (bd == 256).all()
+
+
+def test_many_pairs_property(ctx, oracle):
+    """A slice of config 3 (10k pairs in the bench): 512 pairs, symmetric checks on all, oracle on a sample."""
+    m = ORBmatcher(0.7, ctx=ctx)
+    q, t = synth.descriptor_pairs(100, 512)
+    bi, bd, sd = m.BruteForce(q, t)
+    assert ((bi >= 0) & (bi < 1000)).all() and (bd <= sd).all()
+    # the reported best distance is the true distance to the reported index
+    sel = np.take_along_axis(t, bi[:, :, None].astype(np.int64), axis=1)
+    true = np.unpackbits(q ^ sel, axis=2).sum(2)
+    assert (true == bd).all()
+    for p in (0, 100, 511):
+        rbi, rbd, rsd = oracle.hamming_match(q[p], t[p])
+        assert (bi[p] == rbi).all() and (sd[p] == rsd).all()
+
+
+@pytest.mark.parametrize("kfkf", [False, True])
+def test_search_by_bow(ctx, oracle, kfkf):
+    rng = np.random.default_rng(7)
+    a, b = synth.descriptor_pair(5)
+    n1, n2 = 900, 1000
+    d1, d2 = a[:n1], b[:n2]
+    # give true correspondences the same vocabulary node most of the time
+    node2 = rng.integers(0, 100, n2)
+    bi, _, _ = oracle.hamming_match(d1, d2)
+    node1 = np.where(rng.random(n1) < 0.85, node2[bi], rng.integers(0, 100, n1))
+    node1[rng.random(n1) < 0.02] = -1                           # features without a node
+    v1 = rng.random(n1) < 0.8
+    v2 = (rng.random(n2) < 0.9) if kfkf else None
+    ang2 = rng.random(n2).astype(np.float32) * 360
+    ang1 = (ang2[bi] + rng.normal(0, 4, n1) + 25).astype(np.float32) % 360       # consistent rotation + outliers
+    ang1[rng.random(n1) < 0.1] = rng.random() * 360
+    for ratio, ori in ((0.7, True), (0.75, True), (0.9, False)):
+        m = ORBmatcher(ratio, ori, ctx=ctx)
+        n, mt = m.SearchByBoW(d1, node1, v1, ang1, d2, node2, ang2, valid2=v2)
+        rn, rm = oracle.match_bow(ratio, int(ori), 50, int(kfkf), d1, node1, v1, ang1, d2, node2, v2, ang2)
+        assert n == rn and (mt == rm).all()
+        assert n > 100
+    # one node holding everything == brute force with greedy exclusion
+    m = ORBmatcher(0.7, True, ctx=ctx)
+    z1 = np.zeros(n1, int); z2 = np.zeros(n2, int)
+    n, mt = m.SearchByBoW(d1, z1, v1, ang1, d2, z2, ang2, valid2=v2)
+    rn, rm = oracle.match_bow(0.7, 1, 50, int(kfkf), d1, z1, v1, ang1, d2, z2, v2, ang2)
+    assert n == rn and (mt == rm).all()
+    # empty sides
+    n, mt = m.SearchByBoW(d1[:0], z1[:0], v1[:0], ang1[:0], d2, z2, ang2, valid2=v2)
+    assert n == 0 and len(mt) == 0

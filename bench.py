@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path (BASELINE.json metric).
+
+A "step" is one pass over one batch: ORB-extract 256 synthetic 752x480 frames already resident in
+HBM (8-level pyramid, FAST + quadtree + rBRIEF, BASELINE config 2) and brute-force Hamming match every
+consecutive frame pair on the device (config 3's kernel on the extracted descriptors).  `value` is
+features extracted+matched per second over all ranks (frames are sharded by rank, weak scaling, no
+collective).  The same line also reports global-BA LM iterations/s on the 2000-keyframe / 200k-point
+graph (config 5; landmarks sharded over ranks with one RCCL all-reduce per LM trial), the roofline of
+the dominant kernel, and the CPU oracle timed on this box's host cores.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FRAMES = 256
+W, H = 752, 480
+# algorithmic bytes per 752x480 frame, split by the stage that moves them
+ALG_BYTES = {
+    "k_pyr_resize": 360960 + 756407,                 # read level 0, write levels 1..7
+    "k_fast_score": 1117367,                         # FAST reads every pyramid pixel once
+    "k_cell_nms": 0, "k_octree": 0,                  # candidate lists: not in the survey's figure
+    "k_orient_desc": 2234734 + 1982000,              # blur read+write (fused here) + 1000 kp patches/desc/kp
+}
+ALG_BYTES_FRAME = 6451468
+MATCH_BYTES_PAIR = 76000
+HBM_PEAK_GBS = 8000.0                                # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gba-iters", type=int, default=5)
+    ap.add_argument("--no-gba", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+
+    from motioncheck_ccm_slam_amd import _lib, synth
+    from motioncheck_ccm_slam_amd import dist as D
+    from motioncheck_ccm_slam_amd.orb import ORBextractor
+
+    lib = _lib.load()
+    ctx = _lib.Context(local)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+    m = ex.max_per_image
+
+    # ---- inputs resident in HBM before the timed region
+    frames = synth.frames(rank * FRAMES, FRAMES)
+    img_dev = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    n_pairs = FRAMES - 1
+    bi = torch.empty((n_pairs, m), dtype=torch.int32, device="cuda")
+    bd = torch.empty_like(bi); sd = torch.empty_like(bi)
+
+    def step():
+        ex.extract_dev(img_dev.data_ptr(), W, H, W, W * H, FRAMES)
+        d_ptr, c_ptr, mm = ex.result_dev()
+        ctx.check(lib.ccm_hamming_match_dev(ctx.handle, C.c_void_p(d_ptr), mm, C.c_size_t(mm), C.c_void_p(d_ptr + mm * 32), mm,
+                                            C.c_size_t(mm), n_pairs, C.c_void_p(c_ptr), C.c_void_p(c_ptr + 4),
+                                            C.c_void_p(bi.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(sd.data_ptr())))
+
+    def fence():
+        ctx.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fence()
+    _, _, counts = ex.fetch()
+    feats = int(counts.sum())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ft = torch.tensor([feats], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ft)
+        feats_all = float(ft.item())
+        dist.barrier()
+    else:
+        feats_all = float(feats)
+    ms_per_step = dt / args.steps * 1e3
+    value = feats_all * args.steps / dt / 1e6
+
+    # ---- per-kernel durations: HIP events on the stream the kernels are launched on
+    ctx.profile(True)
+    for _ in range(args.steps):
+        step()
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    kern = {}
+    for k, (ms, n) in prof.items():
+        if n:
+            per_step = ms / args.steps
+            kern[k] = {"ms_per_step": round(per_step, 4), "launches_per_step": n // args.steps}
+    dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: kern[k]["ms_per_step"])
+    dom_bytes = ALG_BYTES[dom] * FRAMES
+    dom_s = kern[dom]["ms_per_step"] * 1e-3
+    achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    extract_ms = sum(v["ms_per_step"] for k, v in kern.items() if k != "k_hamming_bf")
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "pipeline_algorithmic_GBps": round(ALG_BYTES_FRAME * FRAMES / (extract_ms * 1e-3) / 1e9, 2) if extract_ms else None}
+
+    # ---- CPU oracle on this box's host cores (rank 0, N=1 only): the same batch, one core like the reference
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle_py as O
+        par = O.default_params()
+        t1 = time.perf_counter()
+        n_cpu = 0
+        descs = []
+        for f in range(FRAMES):
+            r = O.orb_extract(par, frames[f])
+            n_cpu += len(r["kps"]); descs.append(r["desc"])
+        t2 = time.perf_counter()
+        for f in range(FRAMES - 1):
+            O.hamming_match(descs[f], descs[f + 1])
+        t3 = time.perf_counter()
+        cpu = {"value": round(n_cpu / (t3 - t1) / 1e6, 5), "unit": "Mfeatures/s", "cores": 1, "kind": "port",
+               "sample": "the same %d frames + %d consecutive-pair matches, scalar C oracle on 1 core "
+                         "(extract %.2f s, match %.2f s); host has %d cores" % (FRAMES, FRAMES - 1, t2 - t1, t3 - t2, os.cpu_count())}
+
+    # ---- global BA (config 5): LM iterations per second
+    gba = None
+    if not args.no_gba:
+        try:
+            from motioncheck_ccm_slam_amd.optimizer import Optimizer
+            if world > 1:
+                D.init_comm(ctx, rank, world)
+            g = synth.gba_graph()
+            Optimizer.MapFusionGBA(g, 1, ctx=ctx)                       # warm-up (rocSOLVER init, allocations)
+            fence()
+            tg = time.perf_counter()
+            r = Optimizer.MapFusionGBA(g, args.gba_iters, ctx=ctx)
+            call_s = time.perf_counter() - tg
+            lm_s = r["t_linearize"] + r["t_schur"] + r["t_solve"] + r["t_update"]
+            if world > 1:
+                t = torch.tensor([lm_s, call_s], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                lm_s, call_s = float(t[0]), float(t[1])
+            gba = {"metric": "GBA LM iterations/s (2000 KF, 200k points, %d edges)" % len(g["edge_pose"]),
+                   "iter_per_s": round(r["iterations_done"] / lm_s, 3), "iterations": r["iterations_done"], "trials": r["trials"],
+                   "lm_seconds": round(lm_s, 4), "call_seconds_incl_graph_upload": round(call_s, 4),
+                   "t_linearize": round(r["t_linearize"], 4), "t_schur": round(r["t_schur"], 4),
+                   "t_solve": round(r["t_solve"], 4), "t_update": round(r["t_update"], 4),
+                   "chi2_initial": r["chi2_initial"], "chi2_final": r["chi2_final"], "n_gpus": world, "scaling": "strong",
+                   "dtype": "f64"}
+            if rank == 0 and world == 1 and not args.no_cpu:
+                from oracle import oracle_py as O
+                gs = synth.gba_graph(n_kf=300, n_points=30000, n_agents=3, seed=8)
+                tc = time.perf_counter()
+                rc = O.ba_solve(gs, 3, float(np.sqrt(5.99)))
+                tc = time.perf_counter() - tc
+                gba["cpu_baseline"] = {"value": round(rc["iterations_done"] / tc, 4), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                                       "sample": "300 KF / 30k points / %d edges (the oracle's dense solve does not scale to 2000 KF)" % len(gs["edge_pose"])}
+        except Exception as e:  # the headline number must survive a communicator problem
+            gba = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if rank == 0:
+        out = {
+            "metric": "ORB extract+match Mfeatures/s and GBA iter/s (2k KF, 200k pts) @1/2/4/8 GPU",
+            "value": round(value, 4), "unit": "Mfeatures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 256 synthetic 752x480 frames per GPU, 8-level pyramid, 1000 features, "
+                                   "FAST+quadtree+rBRIEF, then 1000x1000 brute-force Hamming on the 255 consecutive pairs",
+                       "frames_per_gpu": FRAMES, "features_per_step_per_gpu": feats, "pairs_per_step_per_gpu": n_pairs},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "gba": gba,
+            "frames_per_s": round(FRAMES * world * args.steps / dt, 1),
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

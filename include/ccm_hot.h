@@ -47,6 +47,15 @@ int ccm_sync(ccm_ctx*);
 /* The hipStream_t the context launches on (for callers that time with HIP events). */
 void* ccm_stream(ccm_ctx*);
 
+/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline figures).
+ * While enabled, every launch group is bracketed by two events.  ccm_profile_read synchronises,
+ * returns for each label the summed milliseconds and the number of launches since the last read,
+ * and resets the sums.  Labels: see CCM_PROF_*. */
+enum { CCM_PROF_RESIZE = 0, CCM_PROF_FAST_SCORE, CCM_PROF_CELL_NMS, CCM_PROF_OCTREE, CCM_PROF_ORIENT_DESC,
+       CCM_PROF_HAMMING_BF, CCM_PROF_COUNT };
+int ccm_profile_enable(ccm_ctx*, int on);
+int ccm_profile_read(ccm_ctx*, float ms[CCM_PROF_COUNT], int32_t launches[CCM_PROF_COUNT]);
+
 /* ---------------------------------------------------------------- extractor
  * Replaces ORBextractor::ORBextractor (cslam/src/ORBextractor.cpp:579-639) and
  * ORBextractor::operator() (:1216-1278) with its callees ComputePyramid

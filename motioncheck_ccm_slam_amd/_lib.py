@@ -24,6 +24,7 @@ KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), 
 # every symbol include/ccm_hot.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ccm_abi_version", "ccm_create", "ccm_destroy", "ccm_last_error", "ccm_sync", "ccm_stream",
+    "ccm_profile_enable", "ccm_profile_read",
     "ccm_orb_tables", "ccm_orb_level_sizes", "ccm_orb_extract", "ccm_orb_extract_dev", "ccm_orb_fetch",
     "ccm_orb_result_dev", "ccm_orb_debug_level", "ccm_orb_debug_candidates",
     "ccm_descriptor_distance", "ccm_hamming_match", "ccm_hamming_match_dev", "ccm_ratio_test", "ccm_match_bow",
@@ -88,6 +89,8 @@ def load():
     lib.ccm_stream.restype = C.c_void_p
     lib.ccm_stream.argtypes = [C.c_void_p]
     vp = C.c_void_p
+    lib.ccm_profile_enable.argtypes = [vp, C.c_int]
+    lib.ccm_profile_read.argtypes = [vp, vp, vp]
     lib.ccm_orb_tables.argtypes = [C.POINTER(OrbParams)] + [vp] * 6
     lib.ccm_orb_level_sizes.argtypes = [C.POINTER(OrbParams), C.c_int, C.c_int, vp, vp]
     lib.ccm_orb_extract.argtypes = [vp, C.POINTER(OrbParams), vp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
@@ -136,6 +139,17 @@ class Context:
         if rc < 0:
             raise CcmError(rc, self.lib.ccm_last_error(self.handle).decode(errors="replace"))
         return rc
+
+    PROF_LABELS = ("k_pyr_resize", "k_fast_score", "k_cell_nms", "k_octree", "k_orient_desc", "k_hamming_bf")
+
+    def profile(self, on: bool):
+        self.check(self.lib.ccm_profile_enable(self.handle, int(on)))
+
+    def profile_read(self):
+        """{kernel: (total_ms, launches)} since the last read (HIP events on this context's stream)."""
+        ms = np.zeros(len(self.PROF_LABELS), "f4"); n = np.zeros(len(self.PROF_LABELS), "i4")
+        self.check(self.lib.ccm_profile_read(self.handle, ptr(ms), ptr(n)))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PROF_LABELS)}
 
     def sync(self):
         self.check(self.lib.ccm_sync(self.handle))

@@ -39,6 +39,7 @@ void ccm_destroy(ccm_ctx* c)
     orb_state_free(c->orb);
     match_state_free(c->match);
     ba_state_free(c->ba);
+    for (ProfLabel& L : c->prof) for (auto& e : L.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -53,5 +54,30 @@ int ccm_sync(ccm_ctx* c)
 }
 
 void* ccm_stream(ccm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int ccm_profile_enable(ccm_ctx* c, int on)
+{
+    if (!c) return CCM_E_ARG;
+    CCM_HIP(c, hipStreamSynchronize(c->stream));
+    c->prof_on = on != 0;
+    for (ProfLabel& L : c->prof) L.used = 0;
+    return CCM_OK;
+}
+
+int ccm_profile_read(ccm_ctx* c, float ms[CCM_PROF_COUNT], int32_t launches[CCM_PROF_COUNT])
+{
+    if (!c || !ms || !launches) return CCM_E_ARG;
+    CCM_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < CCM_PROF_COUNT; i++) {
+        ProfLabel& L = c->prof[i];
+        float sum = 0;
+        for (size_t k = 0; k < L.used; k++) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, L.ev[k].first, L.ev[k].second) == hipSuccess) sum += t;
+        }
+        ms[i] = sum; launches[i] = (int32_t)L.used; L.used = 0;
+    }
+    return CCM_OK;
+}
 
 }  // extern "C"

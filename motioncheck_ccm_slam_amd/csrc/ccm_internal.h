@@ -14,7 +14,11 @@ struct MatchState;
 struct BaState;
 struct CommState;
 
+struct ProfLabel { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
+
 struct ccm_ctx {
+    bool prof_on = false;
+    ProfLabel prof[CCM_PROF_COUNT];
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -57,6 +61,25 @@ int ccm_fail(ccm_ctx* c, int code, const char* fmt, ...);
             return ccm_fail((c), CCM_E_NOMEM, "%s:%d device alloc of %zu bytes failed",   \
                             __FILE__, __LINE__, (size_t)(bytes));                         \
     } while (0)
+
+// Brackets the launches issued while it is alive with two events when profiling is on.
+struct ProfScope {
+    ccm_ctx* c; int label; hipEvent_t stop = nullptr;
+    ProfScope(ccm_ctx* ctx, int lab) : c(ctx), label(lab)
+    {
+        if (!c->prof_on) return;
+        ProfLabel& L = c->prof[label];
+        if (L.used == L.ev.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            L.ev.emplace_back(a, b);
+        }
+        (void)hipEventRecord(L.ev[L.used].first, c->stream);
+        stop = L.ev[L.used].second;
+        L.used++;
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, c->stream); }
+};
 
 void orb_state_free(OrbState*);
 void match_state_free(MatchState*);

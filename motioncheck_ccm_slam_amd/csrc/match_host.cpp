@@ -54,6 +54,7 @@ int ccm_hamming_match_dev(ccm_ctx* c, const uint8_t* q_dev, int nq, size_t q_pai
         return ccm_fail(c, CCM_E_ARG, "bad matcher arguments (nt must be <= 65535)");
     if (((uintptr_t)q_dev | (uintptr_t)t_dev) & 15) return ccm_fail(c, CCM_E_ARG, "descriptor arrays must be 16-byte aligned");
     CCM_HIP(c, hipSetDevice(c->device));
+    ProfScope ps(c, CCM_PROF_HAMMING_BF);
     match_launch_bf(c->stream, q_dev, (long long)q_pair_stride * 32, t_dev, (long long)t_pair_stride * 32, nq, nt, n_pairs,
                     nq_n_dev, nt_n_dev, best_idx_dev, best_dist_dev, second_dist_dev);
     CCM_HIP(c, hipGetLastError());

@@ -274,15 +274,17 @@ static int orb_run(ccm_ctx* c, const uint8_t* img_dev, int stride, size_t image_
     const OrbCell* cd = S.cells_dev.as<OrbCell>();
     hipStream_t st = c->stream;
     CCM_HIP(c, hipMemsetAsync(S.status.p, 0, 4, st));
-    for (int l = 1; l < G.nlevels; l++) orb_launch_resize(st, gd, l, G.lv[l].w, G.lv[l].h, S.nframes);
-    orb_launch_score(st, gd, G.ntiles, S.nframes);
-    if (G.ncells > 0) orb_launch_nms(st, gd, cd, G.ncells, S.nframes, S.slots.as<unsigned>(), S.cell_count.as<int>());
+    for (int l = 1; l < G.nlevels; l++) { ProfScope ps(c, CCM_PROF_RESIZE); orb_launch_resize(st, gd, l, G.lv[l].w, G.lv[l].h, S.nframes); }
+    { ProfScope ps(c, CCM_PROF_FAST_SCORE); orb_launch_score(st, gd, G.ntiles, S.nframes); }
+    if (G.ncells > 0) { ProfScope ps(c, CCM_PROF_CELL_NMS); orb_launch_nms(st, gd, cd, G.ncells, S.nframes, S.slots.as<unsigned>(), S.cell_count.as<int>()); }
+    { ProfScope ps(c, CCM_PROF_OCTREE);
     orb_launch_octree(st, gd, cd, G.nlevels, S.nframes, G.list_cap, S.slots.as<unsigned>(), S.cell_count.as<int>(),
                       S.keysA.as<unsigned>(), S.keysB.as<unsigned>(), S.sel.as<unsigned>(), S.sel_count.as<int>(),
-                      S.status.as<int>());
+                      S.status.as<int>()); }
+    { ProfScope ps(c, CCM_PROF_ORIENT_DESC);
     orb_launch_orient_desc(st, gd, G.out_per_frame, S.nframes, S.sel.as<unsigned>(), S.sel_count.as<int>(),
                            S.kps.as<ccm_keypoint>(), S.desc.as<uint8_t>(), S.counts.as<int>(), S.max_per_image,
-                           S.status.as<int>());
+                           S.status.as<int>()); }
     CCM_HIP(c, hipGetLastError());
     S.have_result = true;
     return CCM_OK;

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output under gpurun_out/ into the tracked summaries under profiles/.
+
+usage: summarize_prof.py TAG KT_DIR [FETCH_DIR WRITE_DIR]
+  KT_DIR     rocprofv3 --kernel-trace --stats --output-format csv
+  FETCH_DIR  rocprofv3 --pmc FETCH_SIZE  (own pass)      WRITE_DIR  rocprofv3 --pmc WRITE_SIZE (own pass)
+Writes profiles/TAG_kernel_stats.csv, and profiles/pmc_traffic.json (read by bench.py's roofline.traffic).
+HBM bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024: FETCH_SIZE/WRITE_SIZE are in KiB, and gfx950's
+FETCH_SIZE counts half the bytes of a streamed read (MI355X_MICROARCH.md, section HBM).
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, kt = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+
+def short(name):
+    n = name.split("(")[0]
+    if n.startswith("void "): n = n[5:]
+    return n[:70]
+
+rows = []
+for f in glob.glob(os.path.join(kt, "**", "*_kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["Percentage"]),
+                     float(r["MinNs"]), float(r["MaxNs"])))
+rows.sort(key=lambda r: -r[2])
+with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"), "w") as o:
+    o.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
+    for r in rows:
+        o.write("%s,%d,%.0f,%.1f,%.2f,%.0f,%.0f\n" % r)
+print("wrote", tag + "_kernel_stats.csv", len(rows), "kernels")
+
+if len(sys.argv) >= 5:
+    def counter(d, name):
+        acc = defaultdict(lambda: [0.0, 0])
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != name: continue
+                k = short(r["Kernel_Name"])
+                acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+        return acc
+    fe, wr = counter(sys.argv[3], "FETCH_SIZE"), counter(sys.argv[4], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fe) | set(wr)):
+        if not k.startswith("k_"): continue
+        f = fe[k][0] / max(fe[k][1], 1); w = wr[k][0] / max(wr[k][1], 1)
+        out[k] = {"fetch_size_kib_per_launch": round(f, 1), "write_size_kib_per_launch": round(w, 1),
+                  "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024), "launches_sampled": fe[k][1],
+                  "note": "FETCH_SIZE x2 (gfx950 correction for streamed reads; uncalibrated for byte-wide loads) + WRITE_SIZE"}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    for k, v in out.items(): print(k, v["hbm_bytes_per_launch"])

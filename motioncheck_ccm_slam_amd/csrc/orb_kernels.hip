@@ -591,19 +591,42 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-#define OD_SRC_PITCH 44
-#define OD_H_PITCH 38
+// Per-wave LDS: hT[37][46] u16 (horizontally blurred, transposed: column-major so the vertical pass reads
+// a column as 22 consecutive dwords; 92-byte pitch = 23 dwords is odd, hence bank-conflict free) and
+// bl[37][40] u8 (blurred neighbourhood).
+#define OD_HT_PITCH 92
 #define OD_B_PITCH 40
-#define OD_WAVE_LDS (ORB_PATCH_D * OD_SRC_PITCH + ORB_PATCH_D * OD_H_PITCH * 2 + ORB_BLUR_D * OD_B_PITCH + 12)
+#define OD_WAVE_LDS (ORB_BLUR_D * OD_HT_PITCH + ORB_BLUR_D * OD_B_PITCH)      // 3404 + 1480 = 4884
+#define OD_WAVE_LDS_PAD ((OD_WAVE_LDS + 15) & ~15)
 
 __constant__ signed char c_pattern[1024];
+
+typedef unsigned short od_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(od_us2, a), __builtin_bit_cast(od_us2, w), acc, false);
+}
 
 __global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom* __restrict__ g, const unsigned* __restrict__ sel,
                                                      const int* __restrict__ sel_count,
                                                      ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                      int* __restrict__ counts, int max_per_image, int* __restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4][(OD_WAVE_LDS + 15) & ~15];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][OD_WAVE_LDS_PAD];
+    // IC_Angle weights per |v| and patch dword k (columns 4k..4k+3, u = column - 21):
+    //   wone = 1 inside the disc row, wu = u + 16 inside (so that sum u*I = dot(wu) - 16*dot(wone) stays unsigned)
+    __shared__ unsigned wone[16][11], wu[16][11];
+    for (int i = threadIdx.x; i < 16 * 11; i += 256) {
+        const int av = i / 11, k = i - av * 11;
+        const int lim = g->umax[av];
+        unsigned a = 0, b = 0;
+        for (int j = 0; j < 4; j++) {
+            const int u = 4 * k + j - ORB_PATCH_R;
+            if (u >= -lim && u <= lim) { a |= 1u << (8 * j); b |= (unsigned)(u + 16) << (8 * j); }
+        }
+        wone[av][k] = a; wu[av][k] = b;
+    }
+    __syncthreads();
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int slot = blockIdx.x * 4 + wv, f = blockIdx.y;
     if (slot >= g->out_per_frame) return;
@@ -625,48 +648,79 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom* __restrict__
     const int cx = (int)(key & 0xFFFu) + ORB_BORDER, cy = (int)((key >> 12) & 0xFFFu) + ORB_BORDER;   // :1012-1013
     const int score = (int)(key >> 24);
 
-    uint8_t* src = lds[wv];
-    unsigned short* hb = reinterpret_cast<unsigned short*>(src + ORB_PATCH_D * OD_SRC_PITCH);
-    uint8_t* bl = reinterpret_cast<uint8_t*>(hb + ORB_PATCH_D * OD_H_PITCH);
-    const uint8_t* img = L.img + (long long)f * L.plane;
-    for (int i = lane; i < ORB_PATCH_D * ORB_PATCH_D; i += 64) {
-        const int py = i / ORB_PATCH_D, px = i - py * ORB_PATCH_D;
-        const int gy = reflect101(cy + py - ORB_PATCH_R, L.h), gx = reflect101(cx + px - ORB_PATCH_R, L.w);
-        src[py * OD_SRC_PITCH + px] = img[(long long)gy * L.pitch + gx];
+    // ---- lane r < 43 holds patch row r (43 pixels + 1 spare byte) in 11 registers
+    unsigned prow[11];
+    {
+        const uint8_t* img = L.img + (long long)f * L.plane;
+        const int gy = reflect101(cy + min(lane, ORB_PATCH_D - 1) - ORB_PATCH_R, L.h);
+        const uint8_t* rp = img + (long long)gy * L.pitch;
+        if (cx - ORB_PATCH_R >= 0 && cx + ORB_PATCH_R + 1 < L.w) {           // wave-uniform: patch inside the row
+            const uint8_t* p0 = rp + cx - ORB_PATCH_R;
+#pragma unroll
+            for (int i = 0; i < 11; i++) __builtin_memcpy(&prow[i], p0 + 4 * i, 4);   // unaligned dword loads
+        } else {                                                               // BORDER_REFLECT_101 columns
+#pragma unroll
+            for (int i = 0; i < 11; i++) {
+                unsigned v = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v |= (unsigned)rp[reflect101(cx + 4 * i + j - ORB_PATCH_R, L.w)] << (8 * j);
+                prow[i] = v;
+            }
+        }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
 
-    // ---- IC_Angle: integer moments over the radius-15 disc
+    // ---- IC_Angle: integer moments over the radius-15 disc, one row per lane
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int vv = i / 31 - 15, uu = i - (i / 31) * 31 - 15;
-        const int lim = g->umax[vv < 0 ? -vv : vv];
-        if (uu >= -lim && uu <= lim) {
-            const int I = src[(ORB_PATCH_R + vv) * OD_SRC_PITCH + ORB_PATCH_R + uu];
-            m10 += uu * I; m01 += vv * I;
+    {
+        const int v = lane - ORB_PATCH_R, av = v < 0 ? -v : v;
+        if (av <= ORB_HALF_PATCH) {
+            unsigned s1 = 0, su = 0;
+#pragma unroll
+            for (int i = 1; i < 10; i++) {          // columns 4..39 cover u = -15..15 (columns 6..36)
+                s1 = __builtin_amdgcn_udot4(prow[i], wone[av][i], s1, false);
+                su = __builtin_amdgcn_udot4(prow[i], wu[av][i], su, false);
+            }
+            m10 = (int)su - 16 * (int)s1;
+            m01 = v * (int)s1;
         }
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- horizontal 7 taps: rows 0..42, output columns 3..39 of the patch -> hb[row][0..36]
-    for (int i = lane; i < ORB_PATCH_D * ORB_BLUR_D; i += 64) {
-        const int py = i / ORB_BLUR_D, ox = i - py * ORB_BLUR_D;
-        const uint8_t* s = src + py * OD_SRC_PITCH + ox;
-        const int v = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 49 * (s[2] + s[4]) + 55 * s[3];
-        hb[py * OD_H_PITCH + ox] = (unsigned short)v;       // <= 255*257 = 65535
+    uint8_t* wl = lds[wv];
+    uint8_t* bl = wl + ORB_BLUR_D * OD_HT_PITCH;
+    // ---- horizontal 7 taps {18,34,49,55,49,34,18}: two v_dot4_u32_u8 per output, written transposed
+    if (lane < ORB_PATCH_D) {
+        const unsigned Q0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), Q1 = 49u | (34u << 8) | (18u << 16);
+#pragma unroll
+        for (int x = 0; x < ORB_BLUR_D; x++) {
+            const int kk = x >> 2, sh = x & 3;
+            const unsigned w0 = sh ? __builtin_amdgcn_alignbyte(prow[kk + 1], prow[kk], sh) : prow[kk];
+            const unsigned w1 = sh ? __builtin_amdgcn_alignbyte(prow[kk + 2 > 10 ? 10 : kk + 2], prow[kk + 1], sh) : prow[kk + 1];
+            const unsigned h = __builtin_amdgcn_udot4(w1, Q1, __builtin_amdgcn_udot4(w0, Q0, 0u, false), false);   // <= 65535
+            *reinterpret_cast<unsigned short*>(wl + x * OD_HT_PITCH + 2 * lane) = (unsigned short)h;
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    // ---- vertical 7 taps + single rounding: blurred 37x37 neighbourhood
-    for (int i = lane; i < ORB_BLUR_D * ORB_BLUR_D; i += 64) {
-        const int oy = i / ORB_BLUR_D, ox = i - oy * ORB_BLUR_D;
-        const unsigned short* h = hb + oy * OD_H_PITCH + ox;
-        int v = 18 * (h[0] + h[6 * OD_H_PITCH]) + 34 * (h[OD_H_PITCH] + h[5 * OD_H_PITCH]) +
-                49 * (h[2 * OD_H_PITCH] + h[4 * OD_H_PITCH]) + 55 * h[3 * OD_H_PITCH];
-        v = (v + 32768) >> 16;
-        bl[oy * OD_B_PITCH + ox] = (uint8_t)min(v, 255);
+    // ---- vertical 7 taps + the single rounding: lane c < 37 owns blurred column c; rows are packed two per
+    //      dword so four v_dot2_u32_u16 make one output
+    if (lane < ORB_BLUR_D) {
+        unsigned d[22];
+        const unsigned* col = reinterpret_cast<const unsigned*>(wl + lane * OD_HT_PITCH);
+#pragma unroll
+        for (int i = 0; i < 22; i++) d[i] = col[i];
+#pragma unroll
+        for (int y = 0; y < ORB_BLUR_D; y++) {
+            const int kk = y >> 1;
+            unsigned v;
+            if ((y & 1) == 0)
+                v = od_dot2(d[kk + 3], 18u, od_dot2(d[kk + 2], 49u | (34u << 16), od_dot2(d[kk + 1], 49u | (55u << 16), od_dot2(d[kk], 18u | (34u << 16), 0u))));
+            else
+                v = od_dot2(d[kk + 3], 34u | (18u << 16), od_dot2(d[kk + 2], 55u | (49u << 16), od_dot2(d[kk + 1], 34u | (49u << 16), od_dot2(d[kk], 18u << 16, 0u))));
+            v = (v + 32768u) >> 16;
+            bl[y * OD_B_PITCH + lane] = (uint8_t)min(v, 255u);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();

@@ -57,6 +57,34 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom* __restrict__ 
     const uint8_t* r0p = src + (long long)sy0 * S.pitch;
     const uint8_t* r1p = src + (long long)sy1 * S.pitch;
     unsigned out = 0;
+    if (x4 + 3 < D.w) {
+        // tables of the 4 outputs in two 16-byte loads
+        int4 so; uint4 ab;                                   // tables are only 4-/2-byte aligned
+        __builtin_memcpy(&so, D.xofs + x4, 16);
+        __builtin_memcpy(&ab, D.xab + 2 * x4, 16);
+        const int sxs[4] = { so.x, so.y, so.z, so.w };
+        const unsigned abw[4] = { ab.x, ab.y, ab.z, ab.w };
+        const int base = so.x;
+        if (so.w + 1 - base < 8 && base + 8 <= S.w) {
+            // the 4 outputs read source columns base .. base+7 at most: two unaligned 8-byte loads
+            unsigned long long q0, q1;
+            __builtin_memcpy(&q0, r0p + base, 8);
+            __builtin_memcpy(&q1, r1p + base, 8);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int o = sxs[i] - base;
+                const int a0 = (short)(abw[i] & 0xFFFFu), a1 = (short)(abw[i] >> 16);
+                const int p00 = (int)((q0 >> (8 * o)) & 0xFF), p01 = (int)((q0 >> (8 * o + 8)) & 0xFF);
+                const int p10 = (int)((q1 >> (8 * o)) & 0xFF), p11 = (int)((q1 >> (8 * o + 8)) & 0xFF);
+                const int r0 = p00 * a0 + p01 * a1;
+                const int r1 = p10 * a0 + p11 * a1;
+                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                out |= (unsigned)(v & 255) << (8 * i);
+            }
+            *reinterpret_cast<unsigned*>(dst + x4) = out;
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int x = min(x4 + i, D.w - 1);
@@ -104,9 +132,16 @@ __host__ __device__ inline int fast_score16(int v, const int* r)
 #define ST_LW 72           // 64 + 2*4 (3-px halo rounded up to a dword on each side)
 #define ST_LH 22           // 16 + 2*3
 
+// Phase 1: every thread applies the cheap rejection test to its 4 pixels and appends survivors to an LDS
+// list (wave ballot + one LDS atomic per wave).  Phase 2: the list is processed densely, one survivor per
+// lane, so the 100-instruction score never runs on a mostly idle wave.  Phase 3: the 64x16 score tile is
+// written as dwords.
 __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ g)
 {
-    __shared__ uint8_t tile[ST_LH][ST_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[ST_LH][ST_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t outt[ST_H][ST_W];
+    __shared__ unsigned short surv[ST_W * ST_H];
+    __shared__ int nsurv;
     // flattened tile index -> level
     int t = blockIdx.x, level = 0;
     for (int l = 1; l < g->nlevels; l++)
@@ -116,43 +151,71 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
     const int tx0 = (t % L.tiles_x) * ST_W, ty0 = (t / L.tiles_x) * ST_H;
     const int f = blockIdx.y;
     const uint8_t* img = L.img + (long long)f * L.plane;
+    if (threadIdx.x == 0) nsurv = 0;
+    reinterpret_cast<unsigned*>(&outt[0][0])[threadIdx.x] = 0u;
     // stage (clamped) pixels; clamped duplicates are only read by pixels whose score is not needed
-    for (int i = threadIdx.x; i < ST_LH * ST_LW; i += 256) {
-        const int ly = i / ST_LW, lx = i - ly * ST_LW;
-        const int gy = min(max(ty0 + ly - 3, 0), L.h - 1);
-        const int gx = min(max(tx0 + lx - 4, 0), L.w - 1);
-        tile[ly][lx] = img[(long long)gy * L.pitch + gx];
+    const bool dword_ok = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)L.pitch) & 3) == 0 && L.pitch >= ((L.w + 3) & ~3);
+    if (dword_ok) {
+        const int wmax = ((L.w - 1) & ~3);
+        for (int i = threadIdx.x; i < ST_LH * (ST_LW / 4); i += 256) {
+            const int ly = i / (ST_LW / 4), lx = i - ly * (ST_LW / 4);
+            const int gy = min(max(ty0 + ly - 3, 0), L.h - 1);
+            const int gx = min(max(tx0 + 4 * lx - 4, 0), wmax);
+            reinterpret_cast<unsigned*>(&tile[ly][0])[lx] = *reinterpret_cast<const unsigned*>(img + (long long)gy * L.pitch + gx);
+        }
+    } else {
+        for (int i = threadIdx.x; i < ST_LH * ST_LW; i += 256) {
+            const int ly = i / ST_LW, lx = i - ly * ST_LW;
+            const int gy = min(max(ty0 + ly - 3, 0), L.h - 1);
+            const int gx = min(max(tx0 + lx - 4, 0), L.w - 1);
+            tile[ly][lx] = img[(long long)gy * L.pitch + gx];
+        }
     }
     __syncthreads();
     const int px = (threadIdx.x & 15) * 4, py = threadIdx.x >> 4;
     const int gy = ty0 + py;
     const int t_lo = min(g->ini_th, g->min_th);
-    unsigned out = 0;
-    if (gy >= ORB_EDGE && gy < L.h - ORB_EDGE) {
+    const bool row_ok = gy >= ORB_EDGE && gy < L.h - ORB_EDGE;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int gx = tx0 + px + i;
-            if (gx < ORB_EDGE || gx >= L.w - ORB_EDGE) continue;
+    for (int i = 0; i < 4; i++) {
+        const int gx = tx0 + px + i;
+        bool keep = false;
+        if (row_ok && gx >= ORB_EDGE && gx < L.w - ORB_EDGE) {
             const int cy = py + 3, cx = px + i + 4;
             const int v = tile[cy][cx];
             // every 9-arc contains ring pixel k or k+8: both within +-t_lo -> never a corner
             const int n = tile[cy + 3][cx], s = tile[cy - 3][cx];
             const int e = tile[cy][cx + 3], w = tile[cy][cx - 3];
-            const bool rej = (abs(v - n) <= t_lo && abs(v - s) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo);
-            if (rej) continue;
-            int r[16];
-            r[0] = n;                   r[1] = tile[cy + 3][cx + 1];  r[2] = tile[cy + 2][cx + 2];
-            r[3] = tile[cy + 1][cx + 3]; r[4] = e;                    r[5] = tile[cy - 1][cx + 3];
-            r[6] = tile[cy - 2][cx + 2]; r[7] = tile[cy - 3][cx + 1]; r[8] = s;
-            r[9] = tile[cy - 3][cx - 1]; r[10] = tile[cy - 2][cx - 2]; r[11] = tile[cy - 1][cx - 3];
-            r[12] = w;                  r[13] = tile[cy + 1][cx - 3]; r[14] = tile[cy + 2][cx - 2];
-            r[15] = tile[cy + 3][cx - 1];
-            const int sc = fast_score16(v, r);
-            if (sc >= t_lo && sc > 0) out |= (unsigned)sc << (8 * i);
+            keep = !((abs(v - n) <= t_lo && abs(v - s) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo));
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m != 0ull) {
+            int base = 0;
+            if (lane_id() == 0) base = atomicAdd(&nsurv, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (keep) surv[base + __popcll(m & lanemask_lt())] = (unsigned short)(py * ST_W + px + i);
         }
     }
+    __syncthreads();
+    const int ns = nsurv;
+    for (int si = threadIdx.x; si < ns; si += 256) {
+        const int pos = surv[si];
+        const int cy = (pos >> 6) + 3, cx = (pos & 63) + 4;
+        const int v = tile[cy][cx];
+        int r[16];
+        r[0] = tile[cy + 3][cx];      r[1] = tile[cy + 3][cx + 1];  r[2] = tile[cy + 2][cx + 2];
+        r[3] = tile[cy + 1][cx + 3];  r[4] = tile[cy][cx + 3];      r[5] = tile[cy - 1][cx + 3];
+        r[6] = tile[cy - 2][cx + 2];  r[7] = tile[cy - 3][cx + 1];  r[8] = tile[cy - 3][cx];
+        r[9] = tile[cy - 3][cx - 1];  r[10] = tile[cy - 2][cx - 2]; r[11] = tile[cy - 1][cx - 3];
+        r[12] = tile[cy][cx - 3];     r[13] = tile[cy + 1][cx - 3]; r[14] = tile[cy + 2][cx - 2];
+        r[15] = tile[cy + 3][cx - 1];
+        const int sc = fast_score16(v, r);
+        if (sc >= t_lo && sc > 0) outt[pos >> 6][pos & 63] = (uint8_t)sc;
+    }
+    __syncthreads();
     if (gy < L.h && tx0 + px < L.spitch)
-        *reinterpret_cast<unsigned*>(L.smap + (long long)f * L.splane + (long long)gy * L.spitch + tx0 + px) = out;
+        *reinterpret_cast<unsigned*>(L.smap + (long long)f * L.splane + (long long)gy * L.spitch + tx0 + px) =
+            reinterpret_cast<const unsigned*>(&outt[py][0])[px >> 2];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -162,12 +225,13 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
 // outside the detection area count as 0; keep a corner iff its score is strictly greater than its 8
 // neighbours'; output in row-major order.  Candidates go to the cell's slot range as
 // score<<24 | y<<12 | x with x,y relative to minBorderX/Y (the coordinates of vToDistributeKeys).
-#define NMS_PITCH 64      // cells are at most 65 px wide (wCell <= 59, +6): 59+2 columns with the zero ring
-#define NMS_ROWS 62
+#define NMS_PITCH 72      // interior starts at byte 4 of a row (dword aligned), zero ring at byte 3 and after the last column
+#define NMS_ROWS 62       // cells are at most 65 px: 59 detection rows + 2 ring rows
+#define NMS_WAVE_LDS (NMS_PITCH * NMS_ROWS)
 __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g, const OrbCell* __restrict__ cells,
                                                   unsigned* __restrict__ slots, int* __restrict__ cell_count)
 {
-    __shared__ uint8_t lds[4][NMS_ROWS * NMS_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][NMS_WAVE_LDS];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int ci = blockIdx.x * 4 + wv;
     if (ci >= g->ncells) return;
@@ -179,31 +243,49 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g,
     if (rw <= 0 || rh <= 0) { if (lane == 0) *count_out = 0; return; }
     uint8_t* T = lds[wv];
     const uint8_t* sm = L.smap + (long long)f * L.splane;
-    const int lw = rw + 2, lh = rh + 2;
-    // load raw scores with a zero ring
-    for (int i = lane; i < lw * lh; i += 64) {
-        const int yy = i / lw, xx = i - yy * lw;
-        int s = 0;
-        if (yy >= 1 && yy <= rh && xx >= 1 && xx <= rw)
-            s = sm[(long long)(ry0 + yy - 1) * L.spitch + rx0 + xx - 1];
-        T[yy * NMS_PITCH + xx] = (uint8_t)s;
+    // rows 0 and rh+1 of the tile are the zero ring
+    for (int i = lane; i < NMS_PITCH / 4; i += 64) {
+        reinterpret_cast<unsigned*>(T)[i] = 0u;
+        reinterpret_cast<unsigned*>(T + (rh + 1) * NMS_PITCH)[i] = 0u;
     }
+    // interior: 16 lanes x 4 bytes per row (rw <= 59), 4 rows per step; bytes beyond rw are zeroed (they belong
+    // to the neighbouring cell).  The score map has slack behind every plane, so the 4-byte over-read is safe.
+    const int lx = (lane & 15) * 4, lrow = lane >> 4;
+    bool any = false;
+    for (int y0 = 0; y0 < rh; y0 += 4) {
+        const int yy = y0 + lrow;
+        if (yy < rh) {
+            unsigned v = 0;
+            if (lx < rw) {
+                __builtin_memcpy(&v, sm + (long long)(ry0 + yy) * L.spitch + rx0 + lx, 4);
+                const int valid = rw - lx;
+                if (valid < 4) v &= (1u << (8 * valid)) - 1u;
+            }
+            unsigned* dst = reinterpret_cast<unsigned*>(T + (yy + 1) * NMS_PITCH + 4 + lx);
+            *dst = v;
+            if (lane_id() % 16 == 0) *reinterpret_cast<unsigned*>(T + (yy + 1) * NMS_PITCH) = 0u;   // left ring
+            any |= v != 0u;
+        }
+    }
+    if (__ballot(any) == 0ull) { if (lane == 0) *count_out = 0; return; }      // no score >= min(ini,min) anywhere
     __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's LDS stores have landed
     __builtin_amdgcn_wave_barrier();
     unsigned* out = slots + (long long)f * g->slots_per_frame + c.slot_first;
     const int relx = rx0 - ORB_BORDER, rely = ry0 - ORB_BORDER;
     int n = 0;
+    // two rows per step when a row fits 32 lanes; ballot bit order == row-major scan order
+    const int rpi = rw <= 32 ? 2 : 1;
+    const int xx = rpi == 2 ? (lane & 31) : lane, yoff = rpi == 2 ? (lane >> 5) : 0;
     // First iniThFAST; the fallback to minThFAST happens when FAST returned NO KEYPOINT, i.e. after
     // non-max suppression (:981) -- corners that suppress each other with equal scores also trigger it.
     for (int attempt = 0; attempt < 2 && n == 0; attempt++) {
         const int th = attempt == 0 ? g->ini_th : g->min_th;
-        for (int base = 0; base < rw * rh; base += 64) {
-            const int i = base + lane;
+        for (int y0 = 0; y0 < rh; y0 += rpi) {
+            const int yy = y0 + yoff;
             bool keep = false;
-            int yy = 0, xx = 0, s = 0;
-            if (i < rw * rh) {
-                yy = i / rw; xx = i - yy * rw;
-                const uint8_t* p = &T[(yy + 1) * NMS_PITCH + xx + 1];
+            int s = 0;
+            if (yy < rh && xx < rw) {
+                const uint8_t* p = &T[(yy + 1) * NMS_PITCH + 4 + xx];
                 s = p[0];
                 if (s >= th && s > 0) {
                     // scores below the threshold belong to non-corners and count as 0

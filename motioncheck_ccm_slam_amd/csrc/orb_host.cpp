@@ -203,7 +203,7 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
         L.key_first = key_acc; L.key_cap = std::max(key_cap, 1); key_acc += L.key_cap;
         L.out_cap = std::max(L.quota + 4, 4 * L.roots);
         L.out_first = out_acc; out_acc += L.out_cap;
-        L.tiles_x = (L.w + 63) / 64; L.tiles_y = (L.h + 15) / 16;
+        L.tiles_x = (L.w + 63) / 64; L.tiles_y = (L.h + 63) / 64;      // ST_W x ST_H of k_fast_score
         L.tile_first = tile_acc; tile_acc += L.tiles_x * L.tiles_y;
     }
     G.ncells = (int)S.cells.size(); G.ntiles = tile_acc;

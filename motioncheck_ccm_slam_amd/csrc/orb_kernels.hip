@@ -128,14 +128,14 @@ __host__ __device__ inline int fast_score16(int v, const int* r)
 }
 
 #define ST_W 64
-#define ST_H 16
+#define ST_H 64            // tile height: ST_H/16 pixel rows per thread
 #define ST_LW 72           // 64 + 2*4 (3-px halo rounded up to a dword on each side)
-#define ST_LH 22           // 16 + 2*3
+#define ST_LH (ST_H + 6)
 
-// Phase 1: every thread applies the cheap rejection test to its 4 pixels and appends survivors to an LDS
-// list (wave ballot + one LDS atomic per wave).  Phase 2: the list is processed densely, one survivor per
-// lane, so the 100-instruction score never runs on a mostly idle wave.  Phase 3: the 64x16 score tile is
-// written as dwords.
+// Phase 1: every thread applies the cheap rejection test to its pixels (4 adjacent pixels in each of
+// ST_H/16 rows) and appends survivors to an LDS list (wave ballot + one LDS atomic per wave).  Phase 2:
+// the list is processed densely, one survivor per lane, so the 100-instruction score never runs on a
+// mostly idle wave.  Phase 3: the score tile is written as dwords.
 __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ g)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[ST_LH][ST_LW];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
     const int f = blockIdx.y;
     const uint8_t* img = L.img + (long long)f * L.plane;
     if (threadIdx.x == 0) nsurv = 0;
-    reinterpret_cast<unsigned*>(&outt[0][0])[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < ST_H * ST_W / 4; i += 256) reinterpret_cast<unsigned*>(&outt[0][0])[i] = 0u;
     // stage (clamped) pixels; clamped duplicates are only read by pixels whose score is not needed
     const bool dword_ok = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)L.pitch) & 3) == 0 && L.pitch >= ((L.w + 3) & ~3);
     if (dword_ok) {
@@ -172,28 +172,37 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
         }
     }
     __syncthreads();
-    const int px = (threadIdx.x & 15) * 4, py = threadIdx.x >> 4;
-    const int gy = ty0 + py;
+    const int px = (threadIdx.x & 15) * 4;
     const int t_lo = min(g->ini_th, g->min_th);
-    const bool row_ok = gy >= ORB_EDGE && gy < L.h - ORB_EDGE;
+    for (int py = threadIdx.x >> 4; py < ST_H; py += 16) {
+        const int gy = ty0 + py;
+        const bool row_ok = gy >= ORB_EDGE && gy < L.h - ORB_EDGE;
+        const int cy = py + 3;
+        // the 12 bytes around the 4 centre pixels and the 4 bytes three rows below / above, as dwords
+        const unsigned* crow = reinterpret_cast<const unsigned*>(&tile[cy][0]) + (px >> 2);
+        const unsigned c0 = crow[0], c1 = crow[1], c2 = crow[2];
+        const unsigned nn = reinterpret_cast<const unsigned*>(&tile[cy + 3][0])[(px >> 2) + 1];
+        const unsigned ss = reinterpret_cast<const unsigned*>(&tile[cy - 3][0])[(px >> 2) + 1];
+        const unsigned long long lo = ((unsigned long long)c1 << 32) | c0, hi = ((unsigned long long)c2 << 32) | c1;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int gx = tx0 + px + i;
-        bool keep = false;
-        if (row_ok && gx >= ORB_EDGE && gx < L.w - ORB_EDGE) {
-            const int cy = py + 3, cx = px + i + 4;
-            const int v = tile[cy][cx];
-            // every 9-arc contains ring pixel k or k+8: both within +-t_lo -> never a corner
-            const int n = tile[cy + 3][cx], s = tile[cy - 3][cx];
-            const int e = tile[cy][cx + 3], w = tile[cy][cx - 3];
-            keep = !((abs(v - n) <= t_lo && abs(v - s) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo));
-        }
-        const unsigned long long m = __ballot(keep);
-        if (m != 0ull) {
-            int base = 0;
-            if (lane_id() == 0) base = atomicAdd(&nsurv, __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (keep) surv[base + __popcll(m & lanemask_lt())] = (unsigned short)(py * ST_W + px + i);
+        for (int i = 0; i < 4; i++) {
+            const int gx = tx0 + px + i;
+            bool keep = false;
+            if (row_ok && gx >= ORB_EDGE && gx < L.w - ORB_EDGE) {
+                const int v = (int)((c1 >> (8 * i)) & 0xFF);
+                const int n = (int)((nn >> (8 * i)) & 0xFF), s = (int)((ss >> (8 * i)) & 0xFF);
+                const int w = (int)((lo >> (8 * (i + 1))) & 0xFF);         // column cx-3 = byte 4+i-3 of the 12
+                const int e = (int)((hi >> (8 * (i + 3))) & 0xFF);         // column cx+3 = byte 4+i+3
+                // every 9-arc contains ring pixel k or k+8: both within +-t_lo -> never a corner
+                keep = !((abs(v - n) <= t_lo && abs(v - s) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo));
+            }
+            const unsigned long long m = __ballot(keep);
+            if (m != 0ull) {
+                int base = 0;
+                if (lane_id() == 0) base = atomicAdd(&nsurv, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (keep) surv[base + __popcll(m & lanemask_lt())] = (unsigned short)(py * ST_W + px + i);
+            }
         }
     }
     __syncthreads();
@@ -213,9 +222,12 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
         if (sc >= t_lo && sc > 0) outt[pos >> 6][pos & 63] = (uint8_t)sc;
     }
     __syncthreads();
-    if (gy < L.h && tx0 + px < L.spitch)
-        *reinterpret_cast<unsigned*>(L.smap + (long long)f * L.splane + (long long)gy * L.spitch + tx0 + px) =
-            reinterpret_cast<const unsigned*>(&outt[py][0])[px >> 2];
+    for (int py = threadIdx.x >> 4; py < ST_H; py += 16) {
+        const int gy = ty0 + py;
+        if (gy < L.h && tx0 + px < L.spitch)
+            *reinterpret_cast<unsigned*>(L.smap + (long long)f * L.splane + (long long)gy * L.spitch + tx0 + px) =
+                reinterpret_cast<const unsigned*>(&outt[py][0])[px >> 2];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,18 +6,20 @@
 #include <numeric>
 
 void match_launch_bf(hipStream_t, const uint8_t* q, long long q_pair_bytes, const uint8_t* t, long long t_pair_bytes,
-                     int nq, int nt, int n_pairs, const int* nq_n, const int* nt_n, int* bi, int* bd, int* sd);
+                     int nq, int nt, int n_pairs, const int* nq_n, const int* nt_n, int n_split, int variant,
+                     unsigned* part_best, int* part_second, int* bi, int* bd, int* sd);
 void match_launch_ranges(hipStream_t, const uint8_t* d1, const uint8_t* d2, const int* order2, const int* start,
                          const int* len, const long long* off, int n1, unsigned short* dist);
 
 struct MatchState {
     DevBuf q, t, nqn, ntn, bi, bd, sd;          // brute force staging
+    DevBuf part_best, part_second;              // per-split partial results
     DevBuf d1, d2, order2, start, len, off, dist; // BoW staging
 };
 void match_state_free(MatchState* s)
 {
     if (!s) return;
-    DevBuf* all[] = { &s->q, &s->t, &s->nqn, &s->ntn, &s->bi, &s->bd, &s->sd, &s->d1, &s->d2, &s->order2, &s->start, &s->len, &s->off, &s->dist };
+    DevBuf* all[] = { &s->q, &s->t, &s->nqn, &s->ntn, &s->bi, &s->bd, &s->sd, &s->d1, &s->d2, &s->order2, &s->start, &s->len, &s->off, &s->dist, &s->part_best, &s->part_second };
     for (DevBuf* b : all) b->release();
     delete s;
 }
@@ -54,9 +56,22 @@ int ccm_hamming_match_dev(ccm_ctx* c, const uint8_t* q_dev, int nq, size_t q_pai
         return ccm_fail(c, CCM_E_ARG, "bad matcher arguments (nt must be <= 65535)");
     if (((uintptr_t)q_dev | (uintptr_t)t_dev) & 15) return ccm_fail(c, CCM_E_ARG, "descriptor arrays must be 16-byte aligned");
     CCM_HIP(c, hipSetDevice(c->device));
+    if (!c->match) c->match = new MatchState();
+    MatchState& M = *c->match;
+    // Few pairs cannot fill 256 CUs with one workgroup each: split the train rows of a pair over several
+    // workgroups (exact merge afterwards) until there are about four workgroups per CU.
+    static const int env_split = getenv("CCM_BF_SPLIT") ? atoi(getenv("CCM_BF_SPLIT")) : 0;
+    static const int variant = getenv("CCM_BF_VARIANT") ? atoi(getenv("CCM_BF_VARIANT")) : 0;
+    int n_split = env_split > 0 ? env_split : 1;
+    if (env_split <= 0) while (n_split < 8 && (long long)n_pairs * n_split < 1024 && nt / (n_split * 2) >= 128) n_split *= 2;
+    if (n_split > 1) {
+        CCM_RESERVE(c, M.part_best, (size_t)n_pairs * n_split * nq * 4);
+        CCM_RESERVE(c, M.part_second, (size_t)n_pairs * n_split * nq * 4);
+    }
     ProfScope ps(c, CCM_PROF_HAMMING_BF);
     match_launch_bf(c->stream, q_dev, (long long)q_pair_stride * 32, t_dev, (long long)t_pair_stride * 32, nq, nt, n_pairs,
-                    nq_n_dev, nt_n_dev, best_idx_dev, best_dist_dev, second_dist_dev);
+                    nq_n_dev, nt_n_dev, n_split, variant, M.part_best.as<unsigned>(), M.part_second.as<int>(),
+                    best_idx_dev, best_dist_dev, second_dist_dev);
     CCM_HIP(c, hipGetLastError());
     return CCM_OK;
 }

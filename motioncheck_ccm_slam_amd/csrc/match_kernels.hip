@@ -7,7 +7,6 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
-#define BF_THREADS 512
 #define BF_TILE 1024          // train descriptors staged per pass: 32 KiB of LDS
 
 __device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1)
@@ -18,61 +17,110 @@ __device__ __forceinline__ int ham256(const uint4& a0, const uint4& a1, const ui
     return d;
 }
 
-// One workgroup per pair; a lane owns two queries (tid and tid+512) in 16 VGPRs; the train
+// One workgroup per (pair, train split); a lane owns QPL queries (8 VGPRs each); the train
 // descriptors are staged in LDS once per 1024 and read back as wave-uniform (broadcast) b128 loads.
 // Running state per query: best = (dist << 16 | index) so that v_min_u32 keeps the LOWEST index among
 // equal distances, which is what the reference's strict `<` scan in index order keeps; second =
 // min(second, max(dist, best_dist_before)), identical to its if / else-if.
-__global__ __launch_bounds__(BF_THREADS) void k_hamming_bf(
+// With n_split > 1 the train rows of a pair are divided over n_split workgroups that write partial
+// (best, second) to scratch; k_hamming_merge combines them exactly (see there).
+template <int THREADS, int QPL>
+__global__ __launch_bounds__(THREADS) void k_hamming_bf(
     const uint8_t* __restrict__ q, long long q_pair_bytes, const uint8_t* __restrict__ t, long long t_pair_bytes,
-    int nq, int nt, const int* __restrict__ nq_n, const int* __restrict__ nt_n,
+    int nq, int nt, const int* __restrict__ nq_n, const int* __restrict__ nt_n, int n_split,
+    unsigned* __restrict__ part_best, int* __restrict__ part_second,
     int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_dist)
 {
     __shared__ uint4 tile[BF_TILE * 2];
-    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int pair = blockIdx.x / n_split, split = blockIdx.x - pair * n_split, tid = threadIdx.x;
     const int nqp = nq_n ? min(max(nq_n[pair], 0), nq) : nq;
     const int ntp = nt_n ? min(max(nt_n[pair], 0), nt) : nt;
+    // this workgroup's train rows [t_lo, t_hi): equal chunks rounded up to the wave-friendly 64
+    const int chunk = ((ntp + n_split - 1) / n_split + 63) & ~63;
+    const int t_lo = min(split * chunk, ntp), t_hi = min(t_lo + chunk, ntp);
     const uint4* qp = reinterpret_cast<const uint4*>(q + (long long)pair * q_pair_bytes);
     const uint4* tp = reinterpret_cast<const uint4*>(t + (long long)pair * t_pair_bytes);
-    for (int qbase = 0; qbase < nq; qbase += 2 * BF_THREADS) {
-        const int qi0 = qbase + tid, qi1 = qbase + BF_THREADS + tid;
-        const bool live0 = qi0 < nqp, live1 = qi1 < nqp;
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, c0 = a0, c1 = a0;
-        if (live0) { a0 = qp[2 * qi0]; a1 = qp[2 * qi0 + 1]; }
-        if (live1) { c0 = qp[2 * qi1]; c1 = qp[2 * qi1 + 1]; }
-        unsigned bestA = (256u << 16) | 0xFFFFu, bestC = bestA;
-        int secA = 256, secC = 256;
-        for (int tbase = 0; tbase < ntp; tbase += BF_TILE) {
-            const int cnt = min(BF_TILE, ntp - tbase);
+    // rows past the live count only get the "no match" defaults (no train scan for them)
+    const int q_done = ((nqp + QPL * THREADS - 1) / (QPL * THREADS)) * (QPL * THREADS);
+    if (n_split == 1 || split == 0)
+        for (int qi = q_done + tid; qi < nq; qi += THREADS) {
+            if (n_split > 1) {
+                for (int sp = 0; sp < n_split; sp++) {
+                    const long long o = ((long long)pair * n_split + sp) * nq + qi;
+                    part_best[o] = (256u << 16) | 0xFFFFu; part_second[o] = 256;
+                }
+            } else {
+                const long long o = (long long)pair * nq + qi;
+                best_idx[o] = -1; best_dist[o] = 256; second_dist[o] = 256;
+            }
+        }
+    for (int qbase = 0; qbase < nqp; qbase += QPL * THREADS) {
+        uint4 a0[QPL], a1[QPL];
+        unsigned best[QPL]; int sec[QPL];
+#pragma unroll
+        for (int k = 0; k < QPL; k++) {
+            const int qi = qbase + k * THREADS + tid;
+            a0[k] = make_uint4(0, 0, 0, 0); a1[k] = a0[k];
+            if (qi < nqp) { a0[k] = qp[2 * qi]; a1[k] = qp[2 * qi + 1]; }
+            best[k] = (256u << 16) | 0xFFFFu; sec[k] = 256;
+        }
+        for (int tbase = t_lo; tbase < t_hi; tbase += BF_TILE) {
+            const int cnt = min(BF_TILE, t_hi - tbase);
             __syncthreads();
-            for (int i = tid; i < 2 * cnt; i += BF_THREADS) tile[i] = tp[2 * tbase + i];
+            for (int i = tid; i < 2 * cnt; i += THREADS) tile[i] = tp[2 * tbase + i];
             __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
             for (int j = 0; j < cnt; j++) {
                 const uint4 b0 = tile[2 * j], b1 = tile[2 * j + 1];
                 const unsigned idx = (unsigned)(tbase + j);
-                const int dA = ham256(a0, a1, b0, b1);
-                const int dC = ham256(c0, c1, b0, b1);
-                secA = min(secA, max(dA, (int)(bestA >> 16)));
-                secC = min(secC, max(dC, (int)(bestC >> 16)));
-                bestA = min(bestA, ((unsigned)dA << 16) | idx);
-                bestC = min(bestC, ((unsigned)dC << 16) | idx);
+#pragma unroll
+                for (int k = 0; k < QPL; k++) {
+                    const int d = ham256(a0[k], a1[k], b0, b1);
+                    sec[k] = min(sec[k], max(d, (int)(best[k] >> 16)));
+                    best[k] = min(best[k], ((unsigned)d << 16) | idx);
+                }
             }
         }
-        const long long ob = (long long)pair * nq;
-        if (qi0 < nq) {
-            const bool has = live0 && (bestA >> 16) < 256u;
-            best_idx[ob + qi0] = has ? (int)(bestA & 0xFFFFu) : -1;
-            best_dist[ob + qi0] = live0 ? (int)(bestA >> 16) : 256;
-            second_dist[ob + qi0] = live0 ? secA : 256;
-        }
-        if (qi1 < nq) {
-            const bool has = live1 && (bestC >> 16) < 256u;
-            best_idx[ob + qi1] = has ? (int)(bestC & 0xFFFFu) : -1;
-            best_dist[ob + qi1] = live1 ? (int)(bestC >> 16) : 256;
-            second_dist[ob + qi1] = live1 ? secC : 256;
+#pragma unroll
+        for (int k = 0; k < QPL; k++) {
+            const int qi = qbase + k * THREADS + tid;
+            if (qi >= nq) continue;
+            if (n_split > 1) {
+                const long long o = ((long long)pair * n_split + split) * nq + qi;
+                part_best[o] = best[k]; part_second[o] = sec[k];
+            } else {
+                const bool live = qi < nqp;
+                const long long o = (long long)pair * nq + qi;
+                best_idx[o] = (live && (best[k] >> 16) < 256u) ? (int)(best[k] & 0xFFFFu) : -1;
+                best_dist[o] = live ? (int)(best[k] >> 16) : 256;
+                second_dist[o] = live ? sec[k] : 256;
+            }
         }
     }
+}
+
+// Exact merge of per-split partial results over disjoint, ascending index ranges: the overall best is the
+// lexicographic minimum of (dist, index); the overall second-smallest distance is
+// min(max(best_a, best_b), second_a, second_b) folded over the splits in index order.
+__global__ __launch_bounds__(256) void k_hamming_merge(const unsigned* __restrict__ part_best, const int* __restrict__ part_second,
+                                                       int n_pairs, int nq, int n_split, const int* __restrict__ nq_n,
+                                                       int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_dist)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= (long long)n_pairs * nq) return;
+    const int pair = (int)(i / nq), qi = (int)(i - (long long)pair * nq);
+    const int nqp = nq_n ? min(max(nq_n[pair], 0), nq) : nq;
+    unsigned best = (256u << 16) | 0xFFFFu; int sec = 256;
+    for (int s = 0; s < n_split; s++) {
+        const long long o = ((long long)pair * n_split + s) * nq + qi;
+        const unsigned b = part_best[o]; const int sc = part_second[o];
+        sec = min(min(sec, sc), max((int)(best >> 16), (int)(b >> 16)));
+        best = min(best, b);
+    }
+    const bool live = qi < nqp;
+    best_idx[i] = (live && (best >> 16) < 256u) ? (int)(best & 0xFFFFu) : -1;
+    best_dist[i] = live ? (int)(best >> 16) : 256;
+    second_dist[i] = live ? sec : 256;
 }
 
 // Distances of side-1 feature i to the side-2 features order2[start[i] .. start[i]+len[i]) (its vocabulary
@@ -96,11 +144,21 @@ __global__ __launch_bounds__(256) void k_hamming_ranges(
     }
 }
 
+// variant: 0 = 512 threads x 2 queries, 1 = 256 x 4, 2 = 1024 x 1 (tuning knob, CCM_BF_VARIANT)
 void match_launch_bf(hipStream_t s, const uint8_t* q, long long q_pair_bytes, const uint8_t* t, long long t_pair_bytes,
-                     int nq, int nt, int n_pairs, const int* nq_n, const int* nt_n, int* bi, int* bd, int* sd)
+                     int nq, int nt, int n_pairs, const int* nq_n, const int* nt_n, int n_split, int variant,
+                     unsigned* part_best, int* part_second, int* bi, int* bd, int* sd)
 {
-    hipLaunchKernelGGL(k_hamming_bf, dim3(n_pairs), dim3(BF_THREADS), 0, s, q, q_pair_bytes, t, t_pair_bytes,
-                       nq, nt, nq_n, nt_n, bi, bd, sd);
+    const dim3 grid(n_pairs * n_split);
+    if (variant == 1)
+        hipLaunchKernelGGL((k_hamming_bf<256, 4>), grid, dim3(256), 0, s, q, q_pair_bytes, t, t_pair_bytes, nq, nt, nq_n, nt_n, n_split, part_best, part_second, bi, bd, sd);
+    else if (variant == 2)
+        hipLaunchKernelGGL((k_hamming_bf<1024, 1>), grid, dim3(1024), 0, s, q, q_pair_bytes, t, t_pair_bytes, nq, nt, nq_n, nt_n, n_split, part_best, part_second, bi, bd, sd);
+    else
+        hipLaunchKernelGGL((k_hamming_bf<512, 2>), grid, dim3(512), 0, s, q, q_pair_bytes, t, t_pair_bytes, nq, nt, nq_n, nt_n, n_split, part_best, part_second, bi, bd, sd);
+    if (n_split > 1)
+        hipLaunchKernelGGL(k_hamming_merge, dim3((unsigned)(((long long)n_pairs * nq + 255) / 256)), dim3(256), 0, s,
+                           part_best, part_second, n_pairs, nq, n_split, nq_n, bi, bd, sd);
 }
 void match_launch_ranges(hipStream_t s, const uint8_t* d1, const uint8_t* d2, const int* order2, const int* start,
                          const int* len, const long long* off, int n1, unsigned short* dist)

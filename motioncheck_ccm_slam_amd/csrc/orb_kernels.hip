@@ -264,19 +264,26 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g,
     // to the neighbouring cell).  The score map has slack behind every plane, so the 4-byte over-read is safe.
     const int lx = (lane & 15) * 4, lrow = lane >> 4;
     bool any = false;
-    for (int y0 = 0; y0 < rh; y0 += 4) {
-        const int yy = y0 + lrow;
-        if (yy < rh) {
-            unsigned v = 0;
-            if (lx < rw) {
-                __builtin_memcpy(&v, sm + (long long)(ry0 + yy) * L.spitch + rx0 + lx, 4);
-                const int valid = rw - lx;
-                if (valid < 4) v &= (1u << (8 * valid)) - 1u;
+    {
+        // all loads are issued before the first LDS store so that their latencies overlap (rh <= 59: 15 steps)
+        unsigned v[15];
+#pragma unroll
+        for (int it = 0; it < 15; it++) {
+            const int yy = 4 * it + lrow;
+            v[it] = 0;
+            if (yy < rh && lx < rw) __builtin_memcpy(&v[it], sm + (long long)(ry0 + yy) * L.spitch + rx0 + lx, 4);
+        }
+        const int valid = rw - lx;
+        const unsigned keep_mask = valid >= 4 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : (1u << (8 * valid)) - 1u);
+#pragma unroll
+        for (int it = 0; it < 15; it++) {
+            const int yy = 4 * it + lrow;
+            if (yy < rh) {
+                const unsigned w = v[it] & keep_mask;
+                *reinterpret_cast<unsigned*>(T + (yy + 1) * NMS_PITCH + 4 + lx) = w;
+                if ((lane & 15) == 0) *reinterpret_cast<unsigned*>(T + (yy + 1) * NMS_PITCH) = 0u;   // left ring
+                any |= w != 0u;
             }
-            unsigned* dst = reinterpret_cast<unsigned*>(T + (yy + 1) * NMS_PITCH + 4 + lx);
-            *dst = v;
-            if (lane_id() % 16 == 0) *reinterpret_cast<unsigned*>(T + (yy + 1) * NMS_PITCH) = 0u;   // left ring
-            any |= v != 0u;
         }
     }
     if (__ballot(any) == 0ull) { if (lane == 0) *count_out = 0; return; }      // no score >= min(ini,min) anywhere
@@ -296,9 +303,11 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g,
             const int yy = y0 + yoff;
             bool keep = false;
             int s = 0;
-            if (yy < rh && xx < rw) {
-                const uint8_t* p = &T[(yy + 1) * NMS_PITCH + 4 + xx];
-                s = p[0];
+            const uint8_t* p = &T[(min(yy, rh - 1) + 1) * NMS_PITCH + 4 + xx];
+            if (yy < rh && xx < rw) s = p[0];
+            // most rows hold no corner at all: skip the 8 neighbour reads for the whole wave
+            if (__ballot(s >= th && s > 0) == 0ull) continue;
+            {
                 if (s >= th && s > 0) {
                     // scores below the threshold belong to non-corners and count as 0
 #define NB(o) ((int)p[o] >= th ? (int)p[o] : 0)

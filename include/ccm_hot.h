@@ -215,6 +215,11 @@ typedef struct {
     /* per-stage wall seconds, mirroring G2OBatchStatistics (core/batch_stats.h) */
     double t_linearize, t_schur, t_solve, t_update;
     uint8_t* edge_outlier;    /* optional out [n_edges]: chi2 > outlier_chi2 || depth <= 0 at the end (:582) */
+    /* structure of the reduced camera system and work of its solver */
+    int32_t schur_blocks;     /* non-zero 6x6 blocks (upper triangle) */
+    int64_t schur_pairs;      /* (landmark, pose-pair) contributions on this rank */
+    int32_t pcg_iterations;   /* conjugate-gradient iterations, all trials (0 on the dense path) */
+    int32_t pcg_fallbacks;    /* trials that fell back to the dense Cholesky */
 } ccm_ba_result;
 
 int ccm_ba_solve(ccm_ctx*, ccm_ba_problem*, const ccm_ba_options*, ccm_ba_result*);

@@ -64,7 +64,9 @@ class BaResult(C.Structure):
     _fields_ = [("iterations_done", C.c_int), ("trials", C.c_int), ("chi2_initial", C.c_double),
                 ("chi2_final", C.c_double), ("lambda_final", C.c_double), ("stopped", C.c_int),
                 ("t_linearize", C.c_double), ("t_schur", C.c_double), ("t_solve", C.c_double),
-                ("t_update", C.c_double), ("edge_outlier", C.c_void_p)]
+                ("t_update", C.c_double), ("edge_outlier", C.c_void_p),
+                ("schur_blocks", C.c_int32), ("schur_pairs", C.c_int64), ("pcg_iterations", C.c_int32),
+                ("pcg_fallbacks", C.c_int32)]
 
 
 _lib = None

@@ -26,9 +26,33 @@ void ba_launch_pose_rt(hipStream_t, const BaDev&);
 int ba_errors_blocks(const BaDev&);
 void ba_launch_errors(hipStream_t, const BaDev&, double hd, double* partial, double* out);
 void ba_launch_linearize(hipStream_t, const BaDev&, double hd);
-void ba_launch_init_reduced(hipStream_t, const BaDev&, double lambda_diag);
-void ba_launch_add_diag(hipStream_t, const BaDev&, double v);
-void ba_launch_schur(hipStream_t, const BaDev&, double lambda);
+int comm_allreduce_u8_max(ccm_ctx* c, uint8_t* dev, size_t n);
+// ba_sparse.hip
+size_t sp_scan_temp_bytes(size_t n);
+hipError_t sp_scan_int(hipStream_t, void* tmp, size_t tmp_bytes, const int* in, int* out, size_t n);
+hipError_t sp_scan_flags(hipStream_t, void* tmp, size_t tmp_bytes, const uint8_t* in, int* out, size_t n);
+size_t sp_sort_temp_bytes(size_t n);
+hipError_t sp_sort_u64(hipStream_t, void* tmp, size_t tmp_bytes, const unsigned* kin, unsigned* kout, const unsigned long long* vin,
+                       unsigned long long* vout, size_t n, int bits);
+hipError_t sp_sort_u32(hipStream_t, void* tmp, size_t tmp_bytes, const unsigned* kin, unsigned* kout, const unsigned* vin, unsigned* vout, size_t n);
+void sp_launch_pair_count(hipStream_t, const BaDev&, int* cnt);
+void sp_launch_pair_fill(hipStream_t, const BaDev&, const int* off, unsigned* key, unsigned long long* val);
+void sp_launch_mark(hipStream_t, const unsigned* key, long long np, int nfree, uint8_t* map);
+void sp_launch_block_coords(hipStream_t, const uint8_t* map, const int* id, long long n2, int nfree, int* br, int* bc, int* diag);
+void sp_launch_pair_block(hipStream_t, const unsigned* key, const int* id, long long np, unsigned* out);
+void sp_launch_seg_bounds(hipStream_t, const unsigned* sk, long long np, int* st, int* en);
+void sp_launch_row_entries(hipStream_t, const int* br, const int* bc, int nb, int nfree, unsigned* key, unsigned* val);
+void sp_launch_row_ptr(hipStream_t, const unsigned* skey, int n_ent, int nfree, int* row_ptr);
+void sp_launch_dinv(hipStream_t, const BaDev&, double lambda, double* Y, double* db);
+void sp_launch_schur_blocks(hipStream_t, const BaDev&, const double* Y, const unsigned long long* pairs, const int* st, const int* en,
+                            const int* br, const int* bc, int nb, double* Hb);
+void sp_launch_bschur(hipStream_t, const BaDev&, const double* db, double* bs);
+void sp_launch_add_lambda(hipStream_t, const int* diag, int nfree, double lambda, double* Hb);
+void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs);
+void pcg_launch_minv(hipStream_t, const double* Hb, const int* diag, int nfree, double* Minv, int* bad);
+void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc);
+void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
+                     int nfree, double* w, double* pap_part, double* part, double* sc);
 void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_update(hipStream_t, const BaDev&);
 int ba_scale_blocks(const BaDev&);
@@ -41,7 +65,9 @@ struct BaState {
     rocblas_handle blas = nullptr;
     DevBuf poses, Rt, intr, free_of, pose_of_free, points, edge_pose, edge_point, obs, info, active, err,
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
-           partial, scal, flags, info_dev, tmp_ll, pp_diag, gather;
+           partial, scal, flags, info_dev, tmp_ll, pp_diag, gather,
+           sp_cnt, sp_off, sp_key, sp_val, sp_key2, sp_val2, sp_map, sp_id, sp_tmp, blk_row, blk_col, diag_id, seg_start, seg_end,
+           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc;
 };
 void ba_state_free(BaState* s)
 {
@@ -50,7 +76,10 @@ void ba_state_free(BaState* s)
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
                       &s->obs, &s->info, &s->active, &s->err, &s->pt_first, &s->pose_first, &s->pose_edges, &s->Hpp, &s->bp,
                       &s->Hll, &s->bl, &s->Hpl, &s->Dinv, &s->Hs, &s->bs, &s->x, &s->save_poses, &s->save_points,
-                      &s->partial, &s->scal, &s->flags, &s->info_dev, &s->tmp_ll, &s->pp_diag, &s->gather };
+                      &s->partial, &s->scal, &s->flags, &s->info_dev, &s->tmp_ll, &s->pp_diag, &s->gather,
+                      &s->sp_cnt, &s->sp_off, &s->sp_key, &s->sp_val, &s->sp_key2, &s->sp_val2, &s->sp_map, &s->sp_id, &s->sp_tmp, &s->blk_row,
+                      &s->blk_col, &s->diag_id, &s->seg_start, &s->seg_end, &s->ent_key, &s->ent_val, &s->ent_key2, &s->ent_val2, &s->row_ptr,
+                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc };
     for (DevBuf* b : all) b->release();
     delete s;
 }
@@ -192,8 +221,6 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     CCM_RESERVE(c, S.Hpp, std::max<size_t>(36 * (size_t)nfree * 8, 16)); CCM_RESERVE(c, S.bp, std::max<size_t>((size_t)n * 8, 16));
     CCM_RESERVE(c, S.Hll, std::max<size_t>(9 * (size_t)L * 8, 16)); CCM_RESERVE(c, S.bl, std::max<size_t>(3 * (size_t)L * 8, 16));
     CCM_RESERVE(c, S.Hpl, std::max<size_t>(18 * (size_t)E * 8, 16)); CCM_RESERVE(c, S.Dinv, std::max<size_t>(9 * (size_t)L * 8, 16));
-    // Hs and bs are contiguous so that one all-reduce covers both
-    CCM_RESERVE(c, S.Hs, ((size_t)n * n + (size_t)n + 8) * 8);
     CCM_RESERVE(c, S.x, std::max<size_t>(nxl * 8, 16));
     CCM_RESERVE(c, S.save_poses, 7 * (size_t)P * 8); CCM_RESERVE(c, S.save_points, std::max<size_t>(3 * (size_t)L * 8, 16));
     const size_t nb_max = (size_t)std::max((E + 255) / 256, (int)((nxl + 255) / 256)) + 8;
@@ -213,10 +240,71 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     D.pose_first = S.pose_first.as<int>(); D.pose_edges = S.pose_edges.as<int>();
     D.Hpp = S.Hpp.as<double>(); D.bp = S.bp.as<double>(); D.Hll = S.Hll.as<double>(); D.bl = S.bl.as<double>();
     D.Hpl = S.Hpl.as<double>(); D.Dinv = S.Dinv.as<double>();
-    D.Hs = S.Hs.as<double>(); D.bs = D.Hs + (size_t)n * n; D.x = S.x.as<double>();
+    D.Hs = nullptr; D.bs = nullptr; D.x = S.x.as<double>();
     double* scal = S.scal.as<double>();      // [0] chi2, [1] scale, [2] Hll max, ...
     double* partial = S.partial.as<double>();
     int* info_dev = S.info_dev.as<int>();
+
+    // ---- block-sparse structure of the reduced camera system (once per call; see ba_sparse.hip)
+    if ((long long)nfree * nfree >= (1LL << 32)) return ccm_fail(c, CCM_E_ARG, "too many free keyframes (%d) for 32-bit block keys", nfree);
+    const long long n2 = (long long)nfree * nfree;
+    long long NP = 0;
+    int nb = 0;
+    if (nfree > 0) {
+        const size_t scan_tmp = sp_scan_temp_bytes((size_t)std::max<long long>(n2, L + 1));
+        CCM_RESERVE(c, S.sp_cnt, ((size_t)L + 2) * 4); CCM_RESERVE(c, S.sp_off, ((size_t)L + 2) * 4);
+        CCM_RESERVE(c, S.sp_tmp, scan_tmp + 256);
+        CCM_HIP(c, hipMemsetAsync(S.sp_cnt.p, 0, ((size_t)L + 2) * 4, st));
+        if (L > 0) sp_launch_pair_count(st, D, S.sp_cnt.as<int>());
+        CCM_HIP(c, sp_scan_int(st, S.sp_tmp.p, scan_tmp, S.sp_cnt.as<int>(), S.sp_off.as<int>(), (size_t)L + 1));
+        int np_i = 0;
+        CCM_HIP(c, hipMemcpyAsync(&np_i, S.sp_off.as<int>() + L, 4, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        NP = np_i;
+        CCM_RESERVE(c, S.sp_key, std::max<size_t>((size_t)NP * 4, 16)); CCM_RESERVE(c, S.sp_val, std::max<size_t>((size_t)NP * 8, 16));
+        CCM_RESERVE(c, S.sp_key2, std::max<size_t>((size_t)NP * 4, 16)); CCM_RESERVE(c, S.sp_val2, std::max<size_t>((size_t)NP * 8, 16));
+        if (NP > 0) sp_launch_pair_fill(st, D, S.sp_off.as<int>(), S.sp_key.as<unsigned>(), S.sp_val.as<unsigned long long>());
+        CCM_RESERVE(c, S.sp_map, (size_t)n2 + 16); CCM_RESERVE(c, S.sp_id, ((size_t)n2 + 2) * 4);
+        CCM_HIP(c, hipMemsetAsync(S.sp_map.p, 0, (size_t)n2 + 16, st));
+        sp_launch_mark(st, S.sp_key.as<unsigned>(), NP, nfree, S.sp_map.as<uint8_t>());
+        if ((rc = comm_allreduce_u8_max(c, S.sp_map.as<uint8_t>(), (size_t)n2))) return rc;      // union pattern over ranks
+        CCM_HIP(c, sp_scan_flags(st, S.sp_tmp.p, scan_tmp, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), (size_t)n2 + 1));
+        CCM_HIP(c, hipMemcpyAsync(&nb, S.sp_id.as<int>() + n2, 4, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        CCM_RESERVE(c, S.blk_row, (size_t)nb * 4); CCM_RESERVE(c, S.blk_col, (size_t)nb * 4); CCM_RESERVE(c, S.diag_id, (size_t)nfree * 4);
+        sp_launch_block_coords(st, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), n2, nfree, S.blk_row.as<int>(), S.blk_col.as<int>(), S.diag_id.as<int>());
+        // this rank's pairs sorted by target block (stable: fixed summation order)
+        const size_t sort_tmp = sp_sort_temp_bytes((size_t)std::max<long long>(NP, 2LL * nb));
+        CCM_RESERVE(c, S.sp_tmp, std::max(sort_tmp, scan_tmp) + 256);
+        sp_launch_pair_block(st, S.sp_key.as<unsigned>(), S.sp_id.as<int>(), NP, S.sp_key2.as<unsigned>());
+        int bits = 1; while ((1LL << bits) < nb + 1) bits++;
+        if (NP > 0) CCM_HIP(c, sp_sort_u64(st, S.sp_tmp.p, sort_tmp, S.sp_key2.as<unsigned>(), S.sp_key.as<unsigned>(),
+                                           S.sp_val.as<unsigned long long>(), S.sp_val2.as<unsigned long long>(), (size_t)NP, bits));
+        CCM_RESERVE(c, S.seg_start, (size_t)nb * 4); CCM_RESERVE(c, S.seg_end, (size_t)nb * 4);
+        CCM_HIP(c, hipMemsetAsync(S.seg_start.p, 0, (size_t)nb * 4, st)); CCM_HIP(c, hipMemsetAsync(S.seg_end.p, 0, (size_t)nb * 4, st));
+        sp_launch_seg_bounds(st, S.sp_key.as<unsigned>(), NP, S.seg_start.as<int>(), S.seg_end.as<int>());
+        // symmetric row lists for the mat-vec
+        CCM_RESERVE(c, S.ent_key, (size_t)nb * 8); CCM_RESERVE(c, S.ent_val, (size_t)nb * 8);
+        CCM_RESERVE(c, S.ent_key2, (size_t)nb * 8); CCM_RESERVE(c, S.ent_val2, (size_t)nb * 8);
+        sp_launch_row_entries(st, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, nfree, S.ent_key.as<unsigned>(), S.ent_val.as<unsigned>());
+        CCM_HIP(c, sp_sort_u32(st, S.sp_tmp.p, sort_tmp, S.ent_key.as<unsigned>(), S.ent_key2.as<unsigned>(), S.ent_val.as<unsigned>(),
+                               S.ent_val2.as<unsigned>(), (size_t)2 * nb));
+        CCM_RESERVE(c, S.row_ptr, (size_t)nfree * 8);
+        CCM_HIP(c, hipMemsetAsync(S.row_ptr.p, 0, (size_t)nfree * 8, st));
+        sp_launch_row_ptr(st, S.ent_key2.as<unsigned>(), 2 * nb, nfree, S.row_ptr.as<int>());
+        CCM_RESERVE(c, S.Hb, (36 * (size_t)nb + (size_t)n + 8) * 8);          // blocks, then bschur: one all-reduce covers both
+        CCM_RESERVE(c, S.Minv, 36 * (size_t)nfree * 8); CCM_RESERVE(c, S.pcg_w, 5 * (size_t)n * 8 + 64);
+        CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)nfree / 256 + 2) * 3 * 8 + 64);
+        CCM_RESERVE(c, S.pcg_sc, 64 * 8);
+        CCM_HIP(c, hipGetLastError());
+    }
+    CCM_RESERVE(c, S.Y, std::max<size_t>(18 * (size_t)E * 8, 16)); CCM_RESERVE(c, S.db, std::max<size_t>(3 * (size_t)L * 8, 16));
+    double* Hb = S.Hb.as<double>();
+    D.bs = nfree > 0 ? Hb + 36 * (size_t)nb : nullptr;
+    res->schur_blocks = nb; res->schur_pairs = NP;
+    // dense Cholesky for small systems (exact, and cheaper than PCG start-up), PCG on the packed blocks otherwise
+    static const int dense_max = getenv("CCM_BA_DENSE_MAX") ? atoi(getenv("CCM_BA_DENSE_MAX")) : 1536;
+    const bool use_pcg = n > dense_max;
 
     auto stop_requested = [&]() { return opt->stop_flag && *opt->stop_flag; };
     // chi2 (+ optionally scale) of the current state, summed over ranks
@@ -276,27 +364,67 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 auto t1 = clk::now();
                 CCM_HIP(c, hipMemcpyAsync(S.save_poses.p, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));   // push
                 if (L) CCM_HIP(c, hipMemcpyAsync(S.save_points.p, D.points, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
-                CCM_HIP(c, hipMemsetAsync(D.Hs, 0, ((size_t)n * n + (size_t)n) * 8 + 8, st));
-                ba_launch_init_reduced(st, D, 0.0);
-                if (L > 0) ba_launch_schur(st, D, lambda);
-                if ((rc = comm_allreduce_f64(c, D.Hs, (size_t)n * n + (size_t)n, false))) return rc;
-                ba_launch_add_diag(st, D, lambda);
-                CCM_HIP(c, hipStreamSynchronize(st));
-                auto t2 = clk::now();
-                res->t_schur += secs(t1, t2);
                 int ok2 = 1;
-                if (n > 0) {
-                    CCM_HIP(c, hipMemcpyAsync(D.x, D.bs, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-                    // row-major upper triangle == column-major lower triangle
-                    if (rocsolver_dpotrf(S.blas, rocblas_fill_lower, (rocblas_int)n, D.Hs, (rocblas_int)n, info_dev) != rocblas_status_success)
-                        return ccm_fail(c, CCM_E_DEVICE, "rocsolver_dpotrf failed");
-                    int info = 0;
-                    CCM_HIP(c, hipMemcpyAsync(&info, info_dev, 4, hipMemcpyDeviceToHost, st));
+                auto t2 = t1;
+                if (nfree > 0) {
+                    sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>());
+                    sp_launch_schur_blocks(st, D, S.Y.as<double>(), S.sp_val2.as<unsigned long long>(), S.seg_start.as<int>(), S.seg_end.as<int>(),
+                                           S.blk_row.as<int>(), S.blk_col.as<int>(), nb, Hb);
+                    sp_launch_bschur(st, D, S.db.as<double>(), D.bs);
+                    if ((rc = comm_allreduce_f64(c, Hb, 36 * (size_t)nb + (size_t)n, false))) return rc;
+                    sp_launch_add_lambda(st, S.diag_id.as<int>(), nfree, lambda, Hb);
                     CCM_HIP(c, hipStreamSynchronize(st));
-                    ok2 = info == 0;
-                    if (ok2 && rocsolver_dpotrs(S.blas, rocblas_fill_lower, (rocblas_int)n, 1, D.Hs, (rocblas_int)n, D.x, (rocblas_int)n) != rocblas_status_success)
-                        return ccm_fail(c, CCM_E_DEVICE, "rocsolver_dpotrs failed");
+                    t2 = clk::now();
+                    res->t_schur += secs(t1, t2);
+                    bool solved = false;
+                    if (use_pcg) {
+                        int* bad = info_dev + 1;
+                        CCM_HIP(c, hipMemsetAsync(bad, 0, 4, st));
+                        pcg_launch_minv(st, Hb, S.diag_id.as<int>(), nfree, S.Minv.as<double>(), bad);
+                        pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>());
+                        const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
+                        const double tol2 = 1e-13 * 1e-13;
+                        double sc[5] = { 0, 0, 0, 0, 0 };
+                        int itc = 0, badh = 0;
+                        for (;;) {
+                            CCM_HIP(c, hipMemcpyAsync(sc, S.pcg_sc.p, sizeof sc, hipMemcpyDeviceToHost, st));
+                            CCM_HIP(c, hipMemcpyAsync(&badh, bad, 4, hipMemcpyDeviceToHost, st));
+                            CCM_HIP(c, hipStreamSynchronize(st));
+                            if (badh || !(sc[3] > 0.0) || !std::isfinite(sc[2])) { ok2 = 0; solved = true; break; }   // not positive definite
+                            if (sc[2] <= tol2 * sc[1]) { solved = true; break; }
+                            if (itc >= max_it) break;
+                            for (int k = 0; k < 8; k++)
+                                pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>());
+                            itc += 8;
+                        }
+                        res->pcg_iterations += itc;
+                        if (solved && ok2) CCM_HIP(c, hipMemcpyAsync(D.x, S.pcg_w.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+                        if (!solved) res->pcg_fallbacks++;
+                    }
+                    if (!solved) {
+                        CCM_RESERVE(c, S.Hs, ((size_t)n * n + 8) * 8);
+                        double* Hs = S.Hs.as<double>();
+                        CCM_HIP(c, hipMemsetAsync(Hs, 0, (size_t)n * n * 8, st));
+                        sp_launch_to_dense(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, n, Hs);
+                        CCM_HIP(c, hipMemcpyAsync(D.x, D.bs, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+                        // row-major upper block triangle == column-major lower triangle
+                        if (rocsolver_dpotrf(S.blas, rocblas_fill_lower, (rocblas_int)n, Hs, (rocblas_int)n, info_dev) != rocblas_status_success)
+                            return ccm_fail(c, CCM_E_DEVICE, "rocsolver_dpotrf failed");
+                        int info = 0;
+                        CCM_HIP(c, hipMemcpyAsync(&info, info_dev, 4, hipMemcpyDeviceToHost, st));
+                        CCM_HIP(c, hipStreamSynchronize(st));
+                        ok2 = info == 0;
+                        if (ok2 && rocsolver_dpotrs(S.blas, rocblas_fill_lower, (rocblas_int)n, 1, Hs, (rocblas_int)n, D.x, (rocblas_int)n) != rocblas_status_success)
+                            return ccm_fail(c, CCM_E_DEVICE, "rocsolver_dpotrs failed");
+                    }
                     CCM_HIP(c, hipStreamSynchronize(st));
+                } else {
+                    // no free keyframe: only the landmark inverse is needed for the back-substitution
+                    sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>());
+                    CCM_HIP(c, hipStreamSynchronize(st));
+                    t2 = clk::now();
+                    res->t_schur += secs(t1, t2);
                 }
                 auto t3 = clk::now();
                 res->t_solve += secs(t2, t3);

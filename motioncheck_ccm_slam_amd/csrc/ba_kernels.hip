@@ -7,7 +7,7 @@
 //   k_ba_errors       computeActiveErrors + activeRobustChi2            (sparse_optimizer.cpp:61-114)
 //   k_ba_lin_landmark linearizeOplus + constructQuadraticForm, landmark side: Hll, b_l, Hpl per edge
 //   k_ba_lin_pose     the same, pose side: Hpp, b_p (one wave per free pose, fixed summation order)
-//   k_ba_schur        per landmark: Dinv, Hschur -= Hpl Dinv Hpl^T, bschur -= Hpl Dinv b_l
+//   (Schur complement and reduced solve: ba_sparse.hip)
 //   k_ba_backsub      x_l = Dinv (b_l - Hpl^T x_p)                        (block_solver.hpp:461-481)
 //   k_ba_update       oplus on poses (exp map) and points                 (sparse_optimizer.cpp:422-435)
 #include <hip/hip_runtime.h>
@@ -139,65 +139,6 @@ __global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D, double huber_delta
     }
 }
 
-// Hs (n x n row-major, upper block triangle used) = blockdiag(Hpp) [+ lambda I], bs = bp.
-__global__ __launch_bounds__(256) void k_ba_init_reduced(BaDev D, double lambda_diag)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;          // over nfree*36
-    if (i >= D.nfree * 36) return;
-    const int f = i / 36, r = (i % 36) / 6, c = i % 6;
-    const long long n = 6LL * D.nfree;
-    D.Hs[(6LL * f + r) * n + 6 * f + c] = D.Hpp[i] + (r == c ? lambda_diag : 0.0);
-    if (i < D.nfree * 6) D.bs[i] = D.bp[i];
-}
-__global__ __launch_bounds__(256) void k_ba_add_diag(double* Hs, long long n, double v)
-{
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
-    if (i < n) Hs[i * n + i] += v;
-}
-
-// One thread per landmark: Schur complement contributions (block_solver.hpp:381-432) with lambda on
-// the landmark diagonal (setLambda :564-589).  f64 hardware atomics scatter into Hs / bs.
-__global__ __launch_bounds__(128) void k_ba_schur(BaDev D, double lambda)
-{
-    const int l = blockIdx.x * 128 + threadIdx.x;
-    if (l >= D.L) return;
-    double Dm[9], Di[9];
-    for (int i = 0; i < 9; i++) Dm[i] = D.Hll[9 * (long long)l + i];
-    Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
-    ba_inv3(Dm, Di);
-    for (int i = 0; i < 9; i++) D.Dinv[9 * (long long)l + i] = Di[i];
-    const double b0 = D.bl[3 * (long long)l], b1 = D.bl[3 * (long long)l + 1], b2 = D.bl[3 * (long long)l + 2];
-    const double db0 = Di[0] * b0 + Di[1] * b1 + Di[2] * b2;
-    const double db1 = Di[3] * b0 + Di[4] * b1 + Di[5] * b2;
-    const double db2 = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
-    const long long n = 6LL * D.nfree;
-    const int e0 = D.pt_first[l], e1 = D.pt_first[l + 1];
-    for (int a = e0; a < e1; a++) {
-        const int f1 = D.free_of[D.edge_pose[a]];
-        if (f1 < 0 || !D.active[a]) continue;
-        const double* Bi = D.Hpl + 18 * (long long)a;
-        double BD[18];
-        for (int i = 0; i < 6; i++) {
-            const double x = Bi[i * 3], y = Bi[i * 3 + 1], z = Bi[i * 3 + 2];
-            BD[i * 3] = x * Di[0] + y * Di[3] + z * Di[6];
-            BD[i * 3 + 1] = x * Di[1] + y * Di[4] + z * Di[7];
-            BD[i * 3 + 2] = x * Di[2] + y * Di[5] + z * Di[8];
-            unsafeAtomicAdd(D.bs + 6 * f1 + i, -(x * db0 + y * db1 + z * db2));
-        }
-        for (int b = a; b < e1; b++) {
-            const int f2 = D.free_of[D.edge_pose[b]];
-            if (f2 < 0 || !D.active[b]) continue;
-            const double* Bj = D.Hpl + 18 * (long long)b;
-            double* dst = D.Hs + (6LL * f1) * n + 6 * f2;
-            for (int j = 0; j < 6; j++) {
-                const double x = Bj[j * 3], y = Bj[j * 3 + 1], z = Bj[j * 3 + 2];
-                for (int i = 0; i < 6; i++)
-                    unsafeAtomicAdd(dst + i * n + j, -(BD[i * 3] * x + BD[i * 3 + 1] * y + BD[i * 3 + 2] * z));
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev D)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
@@ -289,18 +230,6 @@ void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
 {
     hipLaunchKernelGGL(k_ba_lin_landmark, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);
     if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
-}
-void ba_launch_init_reduced(hipStream_t s, const BaDev& D, double lambda_diag)
-{
-    if (D.nfree > 0) hipLaunchKernelGGL(k_ba_init_reduced, dim3(nblk(D.nfree * 36LL, 256)), dim3(256), 0, s, D, lambda_diag);
-}
-void ba_launch_add_diag(hipStream_t s, const BaDev& D, double v)
-{
-    if (D.nfree > 0) hipLaunchKernelGGL(k_ba_add_diag, dim3(nblk(6LL * D.nfree, 256)), dim3(256), 0, s, D.Hs, 6LL * D.nfree, v);
-}
-void ba_launch_schur(hipStream_t s, const BaDev& D, double lambda)
-{
-    hipLaunchKernelGGL(k_ba_schur, dim3(nblk(D.L, 128)), dim3(128), 0, s, D, lambda);
 }
 void ba_launch_backsub(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_backsub, dim3(nblk(D.L, 256)), dim3(256), 0, s, D); }
 void ba_launch_update(hipStream_t s, const BaDev& D)

@@ -59,3 +59,10 @@ int comm_allreduce_f64(ccm_ctx* c, double* dev, size_t n, bool max_op)
     if (r != ncclSuccess) return ccm_fail(c, CCM_E_COMM, "ncclAllReduce: %s", ncclGetErrorString(r));
     return CCM_OK;
 }
+int comm_allreduce_u8_max(ccm_ctx* c, uint8_t* dev, size_t n)
+{
+    if (!c->comm || c->comm->n_ranks == 1) return CCM_OK;
+    ncclResult_t r = ncclAllReduce(dev, dev, n, ncclUint8, ncclMax, c->comm->comm, c->stream);
+    if (r != ncclSuccess) return ccm_fail(c, CCM_E_COMM, "ncclAllReduce: %s", ncclGetErrorString(r));
+    return CCM_OK;
+}

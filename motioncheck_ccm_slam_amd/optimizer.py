@@ -41,7 +41,9 @@ def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None):
     return dict(poses=keep["poses"], points=keep["points"], outlier=outl[:len(keep["edge_pose"])],
                 iterations_done=res.iterations_done, trials=res.trials, chi2_initial=res.chi2_initial,
                 chi2_final=res.chi2_final, lambda_final=res.lambda_final, stopped=bool(res.stopped),
-                t_linearize=res.t_linearize, t_schur=res.t_schur, t_solve=res.t_solve, t_update=res.t_update)
+                t_linearize=res.t_linearize, t_schur=res.t_schur, t_solve=res.t_solve, t_update=res.t_update,
+                schur_blocks=res.schur_blocks, schur_pairs=res.schur_pairs, pcg_iterations=res.pcg_iterations,
+                pcg_fallbacks=res.pcg_fallbacks)
 
 
 class Optimizer:

@@ -9,13 +9,13 @@
 
 extern "C" hipError_t orb_upload_pattern();
 size_t orb_octree_lds_bytes(int list_cap);
-void orb_launch_resize(hipStream_t, const OrbGeom*, int level, int dw, int dh, int nframes);
-void orb_launch_score(hipStream_t, const OrbGeom*, int ntiles, int nframes);
-void orb_launch_nms(hipStream_t, const OrbGeom*, const OrbCell*, int ncells, int nframes, unsigned* slots, int* cell_count);
-void orb_launch_octree(hipStream_t, const OrbGeom*, const OrbCell*, int nlevels, int nframes, int list_cap,
+void orb_launch_resize(hipStream_t, const OrbGeom&, int level, int dw, int dh, int nframes);
+void orb_launch_score(hipStream_t, const OrbGeom&, int ntiles, int nframes);
+void orb_launch_nms(hipStream_t, const OrbGeom&, const OrbCell*, int ncells, int nframes, unsigned* slots, int* cell_count);
+void orb_launch_octree(hipStream_t, const OrbGeom&, const OrbCell*, int nlevels, int nframes, int list_cap,
                        const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
                        unsigned* out, int* out_count, int* status);
-void orb_launch_orient_desc(hipStream_t, const OrbGeom*, int out_per_frame, int nframes, const unsigned* sel,
+void orb_launch_orient_desc(hipStream_t, const OrbGeom&, int out_per_frame, int nframes, const unsigned* sel,
                             const int* sel_count, ccm_keypoint* kps, uint8_t* desc, int* counts, int max_per_image,
                             int* status);
 
@@ -261,16 +261,9 @@ static int orb_run(ccm_ctx* c, const uint8_t* img_dev, int stride, size_t image_
 {
     OrbState& S = *c->orb;
     OrbGeom& G = S.geom;
-    if (S.last_img != img_dev || S.last_stride != stride || S.last_image_stride != image_stride) {
-        G.lv[0].img = img_dev; G.lv[0].pitch = stride; G.lv[0].plane = (long long)image_stride;
-        // pageable-source async copy would read G after we return; the struct lives in the state, and is
-        // only rewritten here behind a stream sync
-        CCM_HIP(c, hipStreamSynchronize(c->stream));
-        CCM_HIP(c, hipMemcpyAsync(S.geom_dev.p, &G, sizeof G, hipMemcpyHostToDevice, c->stream));
-        CCM_HIP(c, hipStreamSynchronize(c->stream));
-        S.last_img = img_dev; S.last_stride = stride; S.last_image_stride = image_stride;
-    }
-    const OrbGeom* gd = S.geom_dev.as<OrbGeom>();
+    // the geometry table (incl. level 0's image pointer) travels by value in the kernel arguments
+    G.lv[0].img = img_dev; G.lv[0].pitch = stride; G.lv[0].plane = (long long)image_stride;
+    const OrbGeom& gd = G;
     const OrbCell* cd = S.cells_dev.as<OrbCell>();
     hipStream_t st = c->stream;
     CCM_HIP(c, hipMemsetAsync(S.status.p, 0, 4, st));

@@ -41,10 +41,10 @@ __device__ __forceinline__ int wave_sum(int v)
 // Fixed-point bilinear exactly as cv::resize(INTER_LINEAR) for 8-bit data:
 // weights are the host-made 11-bit tables, horizontal pass int32, vertical pass
 // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.
-__global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom* __restrict__ g, int level)
+__global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom g, int level)
 {
-    const OrbLevel& D = g->lv[level];
-    const OrbLevel& S = g->lv[level - 1];
+    const OrbLevel& D = g.lv[level];
+    const OrbLevel& S = g.lv[level - 1];
     const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int f = blockIdx.z;
@@ -136,7 +136,7 @@ __host__ __device__ inline int fast_score16(int v, const int* r)
 // ST_H/16 rows) and appends survivors to an LDS list (wave ballot + one LDS atomic per wave).  Phase 2:
 // the list is processed densely, one survivor per lane, so the 100-instruction score never runs on a
 // mostly idle wave.  Phase 3: the score tile is written as dwords.
-__global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ g)
+__global__ __launch_bounds__(256) void k_fast_score(const OrbGeom g)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[ST_LH][ST_LW];
     __shared__ __attribute__((aligned(16))) uint8_t outt[ST_H][ST_W];
@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
     __shared__ int nsurv;
     // flattened tile index -> level
     int t = blockIdx.x, level = 0;
-    for (int l = 1; l < g->nlevels; l++)
-        if (t >= g->lv[l].tile_first) level = l;
-    const OrbLevel& L = g->lv[level];
+    for (int l = 1; l < g.nlevels; l++)
+        if (t >= g.lv[l].tile_first) level = l;
+    const OrbLevel& L = g.lv[level];
     t -= L.tile_first;
     const int tx0 = (t % L.tiles_x) * ST_W, ty0 = (t / L.tiles_x) * ST_H;
     const int f = blockIdx.y;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
     }
     __syncthreads();
     const int px = (threadIdx.x & 15) * 4;
-    const int t_lo = min(g->ini_th, g->min_th);
+    const int t_lo = min(g.ini_th, g.min_th);
     for (int py = threadIdx.x >> 4; py < ST_H; py += 16) {
         const int gy = ty0 + py;
         const bool row_ok = gy >= ORB_EDGE && gy < L.h - ORB_EDGE;
@@ -184,24 +184,32 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
         const unsigned nn = reinterpret_cast<const unsigned*>(&tile[cy + 3][0])[(px >> 2) + 1];
         const unsigned ss = reinterpret_cast<const unsigned*>(&tile[cy - 3][0])[(px >> 2) + 1];
         const unsigned long long lo = ((unsigned long long)c1 << 32) | c0, hi = ((unsigned long long)c2 << 32) | c1;
+        unsigned keep4 = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int gx = tx0 + px + i;
-            bool keep = false;
             if (row_ok && gx >= ORB_EDGE && gx < L.w - ORB_EDGE) {
                 const int v = (int)((c1 >> (8 * i)) & 0xFF);
                 const int n = (int)((nn >> (8 * i)) & 0xFF), s = (int)((ss >> (8 * i)) & 0xFF);
                 const int w = (int)((lo >> (8 * (i + 1))) & 0xFF);         // column cx-3 = byte 4+i-3 of the 12
                 const int e = (int)((hi >> (8 * (i + 3))) & 0xFF);         // column cx+3 = byte 4+i+3
                 // every 9-arc contains ring pixel k or k+8: both within +-t_lo -> never a corner
-                keep = !((abs(v - n) <= t_lo && abs(v - s) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo));
+                const bool keep = !((abs(v - n) <= t_lo && abs(v - s) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo));
+                keep4 |= keep ? (1u << i) : 0u;
             }
-            const unsigned long long m = __ballot(keep);
-            if (m != 0ull) {
-                int base = 0;
-                if (lane_id() == 0) base = atomicAdd(&nsurv, __popcll(m));
-                base = __shfl(base, 0, 64);
-                if (keep) surv[base + __popcll(m & lanemask_lt())] = (unsigned short)(py * ST_W + px + i);
+        }
+        // survivors are rare: one ballot decides for the whole wave-row
+        if (__ballot(keep4 != 0u) != 0ull) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool keep = (keep4 >> i) & 1u;
+                const unsigned long long m = __ballot(keep);
+                if (m != 0ull) {
+                    int base = 0;
+                    if (lane_id() == 0) base = atomicAdd(&nsurv, __popcll(m));
+                    base = __shfl(base, 0, 64);
+                    if (keep) surv[base + __popcll(m & lanemask_lt())] = (unsigned short)(py * ST_W + px + i);
+                }
             }
         }
     }
@@ -240,18 +248,18 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom* __restrict__ 
 #define NMS_PITCH 72      // interior starts at byte 4 of a row (dword aligned), zero ring at byte 3 and after the last column
 #define NMS_ROWS 62       // cells are at most 65 px: 59 detection rows + 2 ring rows
 #define NMS_WAVE_LDS (NMS_PITCH * NMS_ROWS)
-__global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g, const OrbCell* __restrict__ cells,
+__global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell* __restrict__ cells,
                                                   unsigned* __restrict__ slots, int* __restrict__ cell_count)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][NMS_WAVE_LDS];
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int ci = blockIdx.x * 4 + wv;
-    if (ci >= g->ncells) return;
+    if (ci >= g.ncells) return;
     const int f = blockIdx.y;
     const OrbCell c = cells[ci];
-    const OrbLevel& L = g->lv[c.level];
+    const OrbLevel& L = g.lv[c.level];
     const int rx0 = c.x0 + 3, ry0 = c.y0 + 3, rw = c.cw - 6, rh = c.ch - 6;
-    int* count_out = cell_count + (long long)f * g->ncells + ci;
+    int* count_out = cell_count + (long long)f * g.ncells + ci;
     if (rw <= 0 || rh <= 0) { if (lane == 0) *count_out = 0; return; }
     uint8_t* T = lds[wv];
     const uint8_t* sm = L.smap + (long long)f * L.splane;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g,
     if (__ballot(any) == 0ull) { if (lane == 0) *count_out = 0; return; }      // no score >= min(ini,min) anywhere
     __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): this wave's LDS stores have landed
     __builtin_amdgcn_wave_barrier();
-    unsigned* out = slots + (long long)f * g->slots_per_frame + c.slot_first;
+    unsigned* out = slots + (long long)f * g.slots_per_frame + c.slot_first;
     const int relx = rx0 - ORB_BORDER, rely = ry0 - ORB_BORDER;
     int n = 0;
     // two rows per step when a row fits 32 lanes; ballot bit order == row-major scan order
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom* __restrict__ g,
     // First iniThFAST; the fallback to minThFAST happens when FAST returned NO KEYPOINT, i.e. after
     // non-max suppression (:981) -- corners that suppress each other with equal scores also trigger it.
     for (int attempt = 0; attempt < 2 && n == 0; attempt++) {
-        const int th = attempt == 0 ? g->ini_th : g->min_th;
+        const int th = attempt == 0 ? g.ini_th : g.min_th;
         for (int y0 = 0; y0 < rh; y0 += rpi) {
             const int yy = y0 + yoff;
             bool keep = false;
@@ -377,7 +385,7 @@ __device__ __forceinline__ int oct_nonempty(const int* cc, int p)
     return (cc[4 * p] > 0) + (cc[4 * p + 1] > 0) + (cc[4 * p + 2] > 0) + (cc[4 * p + 3] > 0);
 }
 
-__global__ __launch_bounds__(64) void k_octree(const OrbGeom* __restrict__ g, const OrbCell* __restrict__ cells,
+__global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* __restrict__ cells,
                                                const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
                                                unsigned* keysA, unsigned* keysB,
                                                unsigned* __restrict__ out, int* __restrict__ out_count,
@@ -385,8 +393,8 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom* __restrict__ g, co
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int level = blockIdx.x, f = blockIdx.y, lane = lane_id();
-    const OrbLevel& L = g->lv[level];
-    const int cap = g->list_cap;                                          // multiple of 16
+    const OrbLevel& L = g.lv[level];
+    const int cap = g.list_cap;                                          // multiple of 16
     OctNodes cur = oct_carve(smem, cap);
     OctNodes nxt = oct_carve(smem + (size_t)cap * OCT_SET_BYTES, cap);
     int* cc = reinterpret_cast<int*>(smem + (size_t)cap * 2 * OCT_SET_BYTES);   // [cap][4] child key counts
@@ -396,14 +404,14 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom* __restrict__ g, co
     int* gain = mark + cap;           // careful mode: list growth per candidate, in rank order
     int* shared_len = gain + cap;     // one uniform word
 
-    unsigned* kb[2] = { keysA + (long long)f * g->keys_per_frame + L.key_first,
-                        keysB + (long long)f * g->keys_per_frame + L.key_first };
+    unsigned* kb[2] = { keysA + (long long)f * g.keys_per_frame + L.key_first,
+                        keysB + (long long)f * g.keys_per_frame + L.key_first };
     const int N = L.quota;
-    int* ocount = out_count + (long long)f * g->nlevels + level;
+    int* ocount = out_count + (long long)f * g.nlevels + level;
 
     // ---- gather this level's candidates in cell-major order into kb[0]
-    const int* ccount = cell_count + (long long)f * g->ncells + L.cell_first;
-    const unsigned* fslots = slots + (long long)f * g->slots_per_frame;
+    const int* ccount = cell_count + (long long)f * g.ncells + L.cell_first;
+    const unsigned* fslots = slots + (long long)f * g.slots_per_frame;
     int total = 0;
     for (int base = 0; base < L.ncells; base += 64) {
         const int ci = base + lane;
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom* __restrict__ g, co
     }
 
     // ---- keep the best response of every node, first key wins ties (:912-928); order = list order
-    unsigned* o = out + (long long)f * g->out_per_frame + L.out_first;
+    unsigned* o = out + (long long)f * g.out_per_frame + L.out_first;
     for (int base = 0; base < len; base += 64) {
         const int p = base + lane;
         if (p < len && p < L.out_cap) {
@@ -710,7 +718,7 @@ __device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc
     return __builtin_amdgcn_udot2(__builtin_bit_cast(od_us2, a), __builtin_bit_cast(od_us2, w), acc, false);
 }
 
-__global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom* __restrict__ g, const unsigned* __restrict__ sel,
+__global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
                                                      const int* __restrict__ sel_count,
                                                      ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                      int* __restrict__ counts, int max_per_image, int* __restrict__ status)
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom* __restrict__
     __shared__ unsigned wone[16][11], wu[16][11];
     for (int i = threadIdx.x; i < 16 * 11; i += 256) {
         const int av = i / 11, k = i - av * 11;
-        const int lim = g->umax[av];
+        const int lim = g.umax[av];
         unsigned a = 0, b = 0;
         for (int j = 0; j < 4; j++) {
             const int u = 4 * k + j - ORB_PATCH_R;
@@ -732,22 +740,22 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom* __restrict__
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int slot = blockIdx.x * 4 + wv, f = blockIdx.y;
-    if (slot >= g->out_per_frame) return;
+    if (slot >= g.out_per_frame) return;
     // slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
     int level = 0;
-    for (int l = 1; l < g->nlevels; l++) if (slot >= g->lv[l].out_first) level = l;
-    const OrbLevel& L = g->lv[level];
+    for (int l = 1; l < g.nlevels; l++) if (slot >= g.lv[l].out_first) level = l;
+    const OrbLevel& L = g.lv[level];
     const int k = slot - L.out_first;
-    const int* sc = sel_count + (long long)f * g->nlevels;
+    const int* sc = sel_count + (long long)f * g.nlevels;
     int row = k, tot = 0;
-    for (int l = 0; l < g->nlevels; l++) { const int c = sc[l]; if (l < level) row += c; tot += c; }
+    for (int l = 0; l < g.nlevels; l++) { const int c = sc[l]; if (l < level) row += c; tot += c; }
     if (slot == 0 && lane == 0) {
         counts[f] = min(tot, max_per_image);
         if (tot > max_per_image) atomicOr(status, 8);
     }
+    const unsigned key = sel[(long long)f * g.out_per_frame + slot];      // issued before the count-dependent exit
     if (k >= sc[level] || row >= max_per_image) return;
 
-    const unsigned key = sel[(long long)f * g->out_per_frame + slot];
     const int cx = (int)(key & 0xFFFu) + ORB_BORDER, cy = (int)((key >> 12) & 0xFFFu) + ORB_BORDER;   // :1012-1013
     const int score = (int)(key >> 24);
 
@@ -862,28 +870,28 @@ extern "C" hipError_t orb_upload_pattern()
 
 size_t orb_octree_lds_bytes(int list_cap) { return (size_t)list_cap * OCT_NODE_LDS + 64; }
 
-void orb_launch_resize(hipStream_t s, const OrbGeom* g_dev, int level, int dw, int dh, int nframes)
+void orb_launch_resize(hipStream_t s, const OrbGeom& g_dev, int level, int dw, int dh, int nframes)
 {
     dim3 grid((dw + 255) / 256, (dh + 3) / 4, nframes);
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, g_dev, level);
 }
-void orb_launch_score(hipStream_t s, const OrbGeom* g_dev, int ntiles, int nframes)
+void orb_launch_score(hipStream_t s, const OrbGeom& g_dev, int ntiles, int nframes)
 {
     hipLaunchKernelGGL(k_fast_score, dim3(ntiles, nframes), dim3(256), 0, s, g_dev);
 }
-void orb_launch_nms(hipStream_t s, const OrbGeom* g_dev, const OrbCell* cells, int ncells, int nframes,
+void orb_launch_nms(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int ncells, int nframes,
                     unsigned* slots, int* cell_count)
 {
     hipLaunchKernelGGL(k_cell_nms, dim3((ncells + 3) / 4, nframes), dim3(256), 0, s, g_dev, cells, slots, cell_count);
 }
-void orb_launch_octree(hipStream_t s, const OrbGeom* g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,
+void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,
                        const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
                        unsigned* out, int* out_count, int* status)
 {
     hipLaunchKernelGGL(k_octree, dim3(nlevels, nframes), dim3(64), orb_octree_lds_bytes(list_cap), s,
                        g_dev, cells, slots, cell_count, keysA, keysB, out, out_count, status);
 }
-void orb_launch_orient_desc(hipStream_t s, const OrbGeom* g_dev, int out_per_frame, int nframes, const unsigned* sel,
+void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_frame, int nframes, const unsigned* sel,
                             const int* sel_count, ccm_keypoint* kps, uint8_t* desc, int* counts, int max_per_image,
                             int* status)
 {

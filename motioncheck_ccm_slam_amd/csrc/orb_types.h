@@ -48,3 +48,4 @@ struct OrbGeom {
     int umax[16];
     OrbLevel lv[ORB_MAX_LEVELS];
 };
+static_assert(sizeof(OrbGeom) <= 3584, "OrbGeom is passed by value in the kernel arguments (4 KiB limit)");

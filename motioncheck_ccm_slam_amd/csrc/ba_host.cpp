@@ -52,7 +52,8 @@ void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int*
 void pcg_launch_minv(hipStream_t, const double* Hb, const int* diag, int nfree, double* Minv, int* bad);
 void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc);
 void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc);
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int first);
+void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc);
 void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_update(hipStream_t, const BaDev&);
 int ba_scale_blocks(const BaDev&);
@@ -63,6 +64,7 @@ void ba_launch_deactivate(hipStream_t, const BaDev&, const uint8_t* flag);
 
 struct BaState {
     rocblas_handle blas = nullptr;
+    double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
     DevBuf poses, Rt, intr, free_of, pose_of_free, points, edge_pose, edge_point, obs, info, active, err,
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
            partial, scal, flags, info_dev, tmp_ll, pp_diag, gather,
@@ -73,6 +75,7 @@ void ba_state_free(BaState* s)
 {
     if (!s) return;
     if (s->blas) (void)rocblas_destroy_handle(s->blas);
+    if (s->pinned) (void)hipHostFree(s->pinned);
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
                       &s->obs, &s->info, &s->active, &s->err, &s->pt_first, &s->pose_first, &s->pose_edges, &s->Hpp, &s->bp,
                       &s->Hll, &s->bl, &s->Hpl, &s->Dinv, &s->Hs, &s->bs, &s->x, &s->save_poses, &s->save_points,
@@ -138,6 +141,10 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     if (!S.blas) {
         if (rocblas_create_handle(&S.blas) != rocblas_status_success) { S.blas = nullptr; return ccm_fail(c, CCM_E_DEVICE, "rocblas_create_handle failed"); }
         rocblas_set_stream(S.blas, c->stream);
+    }
+    if (!S.pinned && hipHostMalloc((void**)&S.pinned, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        S.pinned = nullptr;
+        return ccm_fail(c, CCM_E_NOMEM, "hipHostMalloc failed");
     }
     hipStream_t st = c->stream;
     const int ranks = comm_ranks(c), rank = comm_rank(c);
@@ -294,7 +301,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         sp_launch_row_ptr(st, S.ent_key2.as<unsigned>(), 2 * nb, nfree, S.row_ptr.as<int>());
         CCM_RESERVE(c, S.Hb, (36 * (size_t)nb + (size_t)n + 8) * 8);          // blocks, then bschur: one all-reduce covers both
         CCM_RESERVE(c, S.Minv, 36 * (size_t)nfree * 8); CCM_RESERVE(c, S.pcg_w, 5 * (size_t)n * 8 + 64);
-        CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)nfree / 256 + 2) * 3 * 8 + 64);
+        CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)n / 192 + 4) * 3 * 8 + 64);
         CCM_RESERVE(c, S.pcg_sc, 64 * 8);
         CCM_HIP(c, hipGetLastError());
     }
@@ -305,6 +312,28 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // dense Cholesky for small systems (exact, and cheaper than PCG start-up), PCG on the packed blocks otherwise
     static const int dense_max = getenv("CCM_BA_DENSE_MAX") ? atoi(getenv("CCM_BA_DENSE_MAX")) : 1536;
     const bool use_pcg = n > dense_max;
+    // The PCG inner loop is three small dependent kernels per iteration and is launch-bound when issued one by
+    // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
+    const int pcg_chunk = 16;
+    hipGraph_t pcg_graph = nullptr; hipGraphExec_t pcg_exec = nullptr;
+    struct GraphGuard { hipGraph_t& g; hipGraphExec_t& e; ~GraphGuard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } graph_guard{pcg_graph, pcg_exec};
+    if (use_pcg && nfree > 0) {
+        CCM_HIP(c, hipStreamSynchronize(st));
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            for (int k = 0; k < pcg_chunk; k++)
+                pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0);
+            pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
+            hipError_t e1 = hipStreamEndCapture(st, &pcg_graph);
+            hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec, pcg_graph, nullptr, nullptr, 0) : e1;
+            if (e2 != hipSuccess) {
+                pcg_exec = nullptr;                     // fall back to plain launches
+                if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph capture failed: %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
+                (void)hipGetLastError();
+            }
+        } else { if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] hipStreamBeginCapture failed\n"); (void)hipGetLastError(); }
+        if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph %s\n", pcg_exec ? "ready" : "not used");
+    }
 
     auto stop_requested = [&]() { return opt->stop_flag && *opt->stop_flag; };
     // chi2 (+ optionally scale) of the current state, summed over ranks
@@ -315,10 +344,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         if (with_scale) ba_launch_scale(st, D, lambda, rank == 0 ? 1 : 0, partial, scal + 1);
         int r = comm_allreduce_f64(c, scal, with_scale ? 2 : 1, false);
         if (r) return r;
-        double h[2] = { 0, 0 };
-        CCM_HIP(c, hipMemcpyAsync(h, scal, with_scale ? 16 : 8, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipMemcpyAsync(S.pinned + 8, scal, with_scale ? 16 : 8, hipMemcpyDeviceToHost, st));
         CCM_HIP(c, hipStreamSynchronize(st));
-        *chi = h[0]; if (scale) *scale = h[1];
+        *chi = S.pinned[8]; if (scale) *scale = S.pinned[9];
         return CCM_OK;
     };
 
@@ -384,21 +412,29 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>());
                         const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
                         const double tol2 = 1e-13 * 1e-13;
-                        double sc[5] = { 0, 0, 0, 0, 0 };
+                        volatile double* sc = S.pinned;
                         int itc = 0, badh = 0;
+                        CCM_HIP(c, hipMemcpyAsync(&badh, bad, 4, hipMemcpyDeviceToHost, st));
                         for (;;) {
-                            CCM_HIP(c, hipMemcpyAsync(sc, S.pcg_sc.p, sizeof sc, hipMemcpyDeviceToHost, st));
-                            CCM_HIP(c, hipMemcpyAsync(&badh, bad, 4, hipMemcpyDeviceToHost, st));
+                            CCM_HIP(c, hipMemcpyAsync(S.pinned, S.pcg_sc.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
                             CCM_HIP(c, hipStreamSynchronize(st));
                             if (badh || !(sc[3] > 0.0) || !std::isfinite(sc[2])) { ok2 = 0; solved = true; break; }   // not positive definite
                             if (sc[2] <= tol2 * sc[1]) { solved = true; break; }
                             if (itc >= max_it) break;
-                            for (int k = 0; k < 8; k++)
-                                pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>());
-                            itc += 8;
+                            const int reps = itc < 64 ? 2 : 1;             // few host round trips while far from convergence
+                            for (int rpt = 0; rpt < reps; rpt++) {
+                                if (pcg_exec) CCM_HIP(c, hipGraphLaunch(pcg_exec, st));
+                                else {
+                                    for (int k = 0; k < pcg_chunk; k++)
+                                        pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0);
+                                    pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
+                                }
+                            }
+                            itc += reps * pcg_chunk;
                         }
                         res->pcg_iterations += itc;
+                        if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms, rel.res %.2e\n", itc, secs(t2, clk::now()) * 1e3, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)));
                         if (solved && ok2) CCM_HIP(c, hipMemcpyAsync(D.x, S.pcg_w.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
                         if (!solved) res->pcg_fallbacks++;
                     }

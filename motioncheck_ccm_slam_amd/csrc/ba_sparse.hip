@@ -154,24 +154,34 @@ __global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* 
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= nb || lane >= 36) return;
     const int i = lane / 6, j = lane - 6 * i;
-    double s0 = 0, s1 = 0;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     const int p0 = seg_start[b], p1 = seg_end[b];
     int p = p0;
-    for (; p + 1 < p1; p += 2) {                      // two independent chains hide the load latency
-        const unsigned long long v0 = pairs[p], v1 = pairs[p + 1];
-        const double* ya = Y + 18 * (long long)(unsigned)(v0 >> 32) + 3 * i;
-        const double* hb = D.Hpl + 18 * (long long)(unsigned)(v0 & 0xFFFFFFFFu) + 3 * j;
-        const double* yc = Y + 18 * (long long)(unsigned)(v1 >> 32) + 3 * i;
-        const double* hd = D.Hpl + 18 * (long long)(unsigned)(v1 & 0xFFFFFFFFu) + 3 * j;
-        s0 += ya[0] * hb[0] + ya[1] * hb[1] + ya[2] * hb[2];
-        s1 += yc[0] * hd[0] + yc[1] * hd[1] + yc[2] * hd[2];
+    // four independent chains keep four pairs' loads in flight; the grouping is fixed, so the sum is reproducible
+    for (; p + 3 < p1; p += 4) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = pairs[p + q];
+        double ya[4][3], hb[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double* y = Y + 18 * (long long)(unsigned)(v[q] >> 32) + 3 * i;
+            const double* h = D.Hpl + 18 * (long long)(unsigned)(v[q] & 0xFFFFFFFFu) + 3 * j;
+            ya[q][0] = y[0]; ya[q][1] = y[1]; ya[q][2] = y[2];
+            hb[q][0] = h[0]; hb[q][1] = h[1]; hb[q][2] = h[2];
+        }
+        s0 += ya[0][0] * hb[0][0] + ya[0][1] * hb[0][1] + ya[0][2] * hb[0][2];
+        s1 += ya[1][0] * hb[1][0] + ya[1][1] * hb[1][1] + ya[1][2] * hb[1][2];
+        s2 += ya[2][0] * hb[2][0] + ya[2][1] * hb[2][1] + ya[2][2] * hb[2][2];
+        s3 += ya[3][0] * hb[3][0] + ya[3][1] * hb[3][1] + ya[3][2] * hb[3][2];
     }
-    if (p < p1) {
+    for (; p < p1; p++) {
         const unsigned long long v0 = pairs[p];
         const double* ya = Y + 18 * (long long)(unsigned)(v0 >> 32) + 3 * i;
         const double* hb = D.Hpl + 18 * (long long)(unsigned)(v0 & 0xFFFFFFFFu) + 3 * j;
         s0 += ya[0] * hb[0] + ya[1] * hb[1] + ya[2] * hb[2];
     }
+    s0 = (s0 + s1) + (s2 + s3); s1 = 0;
     const int r = blk_row[b], c = blk_col[b];
     const double base = r == c ? D.Hpp[36 * (long long)r + lane] : 0.0;
     Hb[36 * (long long)b + lane] = base - (s0 + s1);
@@ -278,82 +288,110 @@ __global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ 
     sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0;
 }
 
-// Ap = A p for one block row per wave: lanes = 10 entries x 6 rows; fixed-order shuffle reduction
+// Ap = A p, one workgroup per block row: thread = (entry slot 0..41, row component 0..5); the 42 slot sums of a
+// component are added in slot order by one lane (fixed order).  ~130 entries per row -> 3-4 steps per thread and
+// 8000 waves in flight instead of 2000, which is what hides the index->block->data dependent loads.
 __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb, const int* __restrict__ row_ptr, const unsigned* __restrict__ ent_key,
-                                                  const unsigned* __restrict__ ent_val, int nfree, double* __restrict__ w, double* __restrict__ pap_part)
+                                                  const unsigned* __restrict__ ent_val, int nfree, double* __restrict__ w, double* __restrict__ pap_part,
+                                                  int publish, int nblk_part, const double* __restrict__ part, double* __restrict__ sc)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= nfree) return;
+    __shared__ double red[42][6];
+    // The scalars of the PREVIOUS iteration (r.z, |r|^2, p.Ap) are published here, after k_pcg_dir has consumed
+    // the old r.z and before this iteration's k_pcg_update reads the new one (kernel boundaries order both).
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+        double rz = 0, rr = 0;
+        for (int i = 0; i < nblk_part; i++) { rz += part[3 * i]; rr += part[3 * i + 1]; }
+        const double pap = part[2];
+        sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;
+    }
+    const int row = blockIdx.x;
     const long long n = 6LL * nfree;
     const double* p = w + 3 * n;
-    const int slot = lane / 6, r = lane - 6 * slot;          // slots 0..9, lanes 60..63 idle
-    double acc = 0;
-    if (slot < 10) {
-        for (int k = row_ptr[2 * row] + slot; k < row_ptr[2 * row + 1]; k += 10) {
-            const unsigned v = ent_val[k];
-            const int col = (int)(ent_key[k] - (unsigned)row * (unsigned)nfree);
-            const double* B = Hb + 36 * (long long)(v & 0x7FFFFFFFu);
-            const double* x = p + 6 * (long long)col;
-            if (v & 0x80000000u) {
-                for (int c = 0; c < 6; c++) acc += B[c * 6 + r] * x[c];          // transposed block
-            } else {
-                for (int c = 0; c < 6; c++) acc += B[r * 6 + c] * x[c];
+    const int slot = threadIdx.x / 6, r = threadIdx.x - 6 * slot;
+    if (slot < 42) {
+        double acc = 0;
+        const int k_end = row_ptr[2 * row + 1];
+        // four entries per step: all index loads are issued first, then all block / vector loads, so a row of
+        // up to 168 blocks costs two dependent memory round trips instead of eight
+        for (int k0 = row_ptr[2 * row] + slot; k0 < k_end; k0 += 4 * 42) {
+            unsigned v[4]; int col[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int k = k0 + 42 * q;
+                v[q] = 0xFFFFFFFFu; col[q] = 0;
+                if (k < k_end) { v[q] = ent_val[k]; col[q] = (int)(ent_key[k] - (unsigned)row * (unsigned)nfree); }
             }
+            double bv[4][6], xv[4][6];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (v[q] == 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) { bv[q][c] = 0; xv[q][c] = 0; }
+                    continue;
+                }
+                const double* B = Hb + 36 * (long long)(v[q] & 0x7FFFFFFFu);
+                const double* x = p + 6 * (long long)col[q];
+                const bool tr = (v[q] & 0x80000000u) != 0u;
+#pragma unroll
+                for (int c = 0; c < 6; c++) { bv[q][c] = tr ? B[c * 6 + r] : B[r * 6 + c]; xv[q][c] = x[c]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc += bv[q][c] * xv[q][c];
         }
+        red[slot][r] = acc;
     }
-    // sum the 10 slots of each row component: bring lane (slot, r) to lane r
-    double tot = 0;
-    for (int s = 0; s < 10; s++) {
-        const double v = __shfl(acc, s * 6 + (lane % 6), 64);
-        tot += v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double tot = 0, pap = 0;
+        if (threadIdx.x < 6) {
+            for (int s2 = 0; s2 < 42; s2++) tot += red[s2][threadIdx.x];
+            w[4 * n + 6LL * row + threadIdx.x] = tot;
+            pap = tot * p[6LL * row + threadIdx.x];
+        }
+        for (int st = 4; st >= 1; st >>= 1) pap += __shfl_xor(pap, st, 64);     // lanes 0..7 (6,7 hold 0)
+        if (threadIdx.x == 0) pap_part[row] = pap;
     }
-    double pap = 0;
-    if (lane < 6) {
-        w[4 * n + 6LL * row + lane] = tot;
-        pap = tot * p[6LL * row + lane];
-    }
-    for (int s = 4; s >= 1; s >>= 1) pap += __shfl_xor(pap, s, 64);     // lanes 0..7 (6,7 hold 0)
-    if (lane == 0) pap_part[row] = pap;
 }
 
-// x += alpha p; r -= alpha Ap; z = Minv r; partial r.z and r.r.  Every block re-reduces p.Ap (nfree values) itself.
-__global__ __launch_bounds__(256) void k_pcg_update(const double* __restrict__ Minv, int nfree, double* __restrict__ w,
-                                                    const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part)
+// x += alpha p; r -= alpha Ap; z = Minv r; partial r.z and r.r.  One thread per scalar unknown (the six new
+// residual components of its pose are recomputed locally).  Every block re-reduces p.Ap (nfree values) itself.
+#define PCG_UPD_TPB 192       // a multiple of 6: the six scalars of a pose never straddle two blocks
+__global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __restrict__ Minv, int nfree, double* __restrict__ w,
+                                                            const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part)
 {
     __shared__ double red[256];
-    __shared__ double red2[2][4];
+    __shared__ double red2[2][3];
     double s = 0;
-    for (int i = threadIdx.x; i < nfree; i += 256) s += pap_part[i];
+    for (int i = threadIdx.x; i < nfree; i += PCG_UPD_TPB) s += pap_part[i];
     red[threadIdx.x] = s;
+    if (threadIdx.x < 64) red[PCG_UPD_TPB + threadIdx.x] = 0.0;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
     const double pap = red[0];
     const double rz_old = sc[0];
     const double alpha = pap > 0.0 ? rz_old / pap : 0.0;
-    const int f = blockIdx.x * 256 + threadIdx.x;
     const long long n = 6LL * nfree;
-    double rz = 0, rr = 0;
-    if (f < nfree) {
-        double r[6];
-        for (int i = 0; i < 6; i++) {
-            const long long o = 6LL * f + i;
-            w[o] += alpha * w[3 * n + o];
-            r[i] = w[n + o] - alpha * w[4 * n + o];
-            w[n + o] = r[i];
-        }
-        for (int i = 0; i < 6; i++) {
-            double z = 0;
-            for (int j = 0; j < 6; j++) z += Minv[36 * (long long)f + i * 6 + j] * r[j];
-            w[2 * n + 6LL * f + i] = z;
-            rz += r[i] * z; rr += r[i] * r[i];
-        }
+    const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
+    double rz = 0, rr = 0, xi = 0, ri = 0, z = 0;
+    if (o < n) {
+        const long long f = o / 6; const int i = (int)(o - 6 * f);
+        double rn[6];
+        for (int j = 0; j < 6; j++) rn[j] = w[n + 6 * f + j] - alpha * w[4 * n + 6 * f + j];
+        for (int j = 0; j < 6; j++) z += Minv[36 * f + i * 6 + j] * rn[j];
+        xi = w[o] + alpha * w[3 * n + o];
+        ri = rn[i];
+        rz = ri * z; rr = ri * ri;
     }
+    __syncthreads();                          // every thread of the block has read the old residual of its pose
+    if (o < n) { w[o] = xi; w[n + o] = ri; w[2 * n + o] = z; }
     for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); }
     if ((threadIdx.x & 63) == 0) { red2[0][threadIdx.x >> 6] = rz; red2[1][threadIdx.x >> 6] = rr; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[3 * blockIdx.x] = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
-        part[3 * blockIdx.x + 1] = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
+        part[3 * blockIdx.x] = (red2[0][0] + red2[0][1]) + red2[0][2];
+        part[3 * blockIdx.x + 1] = (red2[1][0] + red2[1][1]) + red2[1][2];
         part[3 * blockIdx.x + 2] = pap;
     }
 }
@@ -451,12 +489,17 @@ void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfr
     hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(256), 0, s, b, Minv, nfree, w, part);
     hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, sc);
 }
+// `first` = this is the first iteration since pcg_launch_init or pcg_launch_publish (nothing pending to publish)
 void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc)
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int first)
 {
-    const int nb = nblk(nfree, 256);
-    hipLaunchKernelGGL(k_pcg_spmv, dim3(nblk(nfree, 4)), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part);
-    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, s, Minv, nfree, w, pap_part, sc, part);
+    const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(nfree), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, first ? 0 : 1, nb, part, sc);
+    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part);
     hipLaunchKernelGGL(k_pcg_dir, dim3(nblk(6LL * nfree, 256)), dim3(256), 0, s, nfree, nb, w, part, sc);
-    hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nb, part, sc);
+}
+// publish the scalars of the last iteration (before the host reads them)
+void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc)
+{
+    hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nblk(6LL * nfree, PCG_UPD_TPB), part, sc);
 }

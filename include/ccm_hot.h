@@ -224,6 +224,25 @@ typedef struct {
 
 int ccm_ba_solve(ccm_ctx*, ccm_ba_problem*, const ccm_ba_options*, ccm_ba_result*);
 
+/* Optimizer::PoseOptimizationClient (src/Optimizer.cpp:215-347), batched over frames: one free pose per
+ * frame, one unary EdgeSE3ProjectXYZOnlyPose per frame feature with a MapPoint, Huber sqrt(5.991), four
+ * rounds of optimize(10) restarted from the input pose, chi2 > 5.991 relabels outliers after each round.
+ * Correspondences of frame f are rows first[f] .. first[f+1]-1 of points/obs/info.  On return poses holds
+ * the optimised Tcw, outlier[] is Frame::mvbOutlier, n_inliers[f] the function's return value
+ * (nInitialCorrespondences - nBad; 0 with fewer than 3 correspondences, pose untouched). */
+typedef struct {
+    int            n_frames;
+    double*        poses;      /* [n_frames][7] in/out */
+    const double*  intr;       /* [n_frames][4] fx fy cx cy */
+    const int32_t* first;      /* [n_frames+1] */
+    const double*  points;     /* [first[n_frames]][3] MapPoint world positions */
+    const double*  obs;        /* [..][2] undistorted keypoints */
+    const double*  info;       /* [..] invSigma2 of the keypoint's octave */
+    uint8_t*       outlier;    /* [..] out */
+    int32_t*       n_inliers;  /* [n_frames] out */
+} ccm_pose_problem;
+int ccm_pose_optimize(ccm_ctx*, ccm_pose_problem*);
+
 /* Multi-GPU GBA: every rank calls ccm_ba_solve with the
  * SAME poses and ITS OWN landmark partition (points + their edges); the reduced
  * camera system is summed with one RCCL all-reduce per LM trial.  One rank

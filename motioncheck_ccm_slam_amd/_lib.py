@@ -28,7 +28,7 @@ SYMBOLS = [
     "ccm_orb_tables", "ccm_orb_level_sizes", "ccm_orb_extract", "ccm_orb_extract_dev", "ccm_orb_fetch",
     "ccm_orb_result_dev", "ccm_orb_debug_level", "ccm_orb_debug_candidates",
     "ccm_descriptor_distance", "ccm_hamming_match", "ccm_hamming_match_dev", "ccm_ratio_test", "ccm_match_bow",
-    "ccm_ba_solve", "ccm_comm_unique_id", "ccm_comm_init", "ccm_comm_destroy",
+    "ccm_ba_solve", "ccm_pose_optimize", "ccm_comm_unique_id", "ccm_comm_init", "ccm_comm_destroy",
     "ccm_pose_from_mat4f", "ccm_pose_to_mat4f",
 ]
 
@@ -53,6 +53,12 @@ class BaProblem(C.Structure):
                 ("n_points", C.c_int), ("points", C.c_void_p),
                 ("n_edges", C.c_int), ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p),
                 ("obs", C.c_void_p), ("info", C.c_void_p)]
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("poses", C.c_void_p), ("intr", C.c_void_p), ("first", C.c_void_p),
+                ("points", C.c_void_p), ("obs", C.c_void_p), ("info", C.c_void_p), ("outlier", C.c_void_p),
+                ("n_inliers", C.c_void_p)]
 
 
 class BaOptions(C.Structure):
@@ -110,6 +116,7 @@ def load():
     lib.ccm_ratio_test.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]
     lib.ccm_match_bow.argtypes = [vp, C.POINTER(BowOptions), vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     lib.ccm_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaResult)]
+    lib.ccm_pose_optimize.argtypes = [vp, C.POINTER(PoseProblem)]
     lib.ccm_comm_unique_id.argtypes = [vp]
     lib.ccm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.ccm_comm_destroy.argtypes = [vp]

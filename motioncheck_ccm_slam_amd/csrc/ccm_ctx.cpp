@@ -39,6 +39,7 @@ void ccm_destroy(ccm_ctx* c)
     orb_state_free(c->orb);
     match_state_free(c->match);
     ba_state_free(c->ba);
+    pose_state_free(c->pose);
     for (ProfLabel& L : c->prof) for (auto& e : L.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -13,6 +13,7 @@ struct OrbState;
 struct MatchState;
 struct BaState;
 struct CommState;
+struct PoseState;
 
 struct ProfLabel { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
 
@@ -26,6 +27,7 @@ struct ccm_ctx {
     MatchState* match = nullptr;
     BaState* ba = nullptr;
     CommState* comm = nullptr;
+    PoseState* pose = nullptr;
 };
 
 // grow-only device buffer
@@ -85,3 +87,4 @@ void orb_state_free(OrbState*);
 void match_state_free(MatchState*);
 void ba_state_free(BaState*);
 void comm_state_free(ccm_ctx*);
+void pose_state_free(PoseState*);

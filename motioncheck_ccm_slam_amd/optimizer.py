@@ -68,6 +68,23 @@ class Optimizer:
         return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag)
 
 
+    @staticmethod
+    def PoseOptimizationClient(poses, intr, first, points, obs, info, ctx=None):
+        """Batched Optimizer::PoseOptimizationClient (src/Optimizer.cpp:215-347).  Frame f's correspondences are
+        rows first[f]..first[f+1]-1.  Returns (poses, outlier flags, n_inliers per frame)."""
+        ctx = ctx or _lib.default_context(0)
+        lib = _lib.load()
+        poses = np.ascontiguousarray(poses, "f8").copy(); intr = np.ascontiguousarray(intr, "f8")
+        first = np.ascontiguousarray(first, "i4"); points = np.ascontiguousarray(points, "f8")
+        obs = np.ascontiguousarray(obs, "f8"); info = np.ascontiguousarray(info, "f8")
+        nf = len(poses)
+        outl = np.zeros(max(len(info), 1), np.uint8); ninl = np.zeros(nf, "i4")
+        p = _lib.ptr
+        pb = _lib.PoseProblem(nf, p(poses), p(intr), p(first), p(points), p(obs), p(info), p(outl), p(ninl))
+        ctx.check(lib.ccm_pose_optimize(ctx.handle, C.byref(pb)))
+        return poses, outl[:len(info)], ninl
+
+
 def pose_from_mat4f(T: np.ndarray) -> np.ndarray:
     T = np.ascontiguousarray(T, np.float32); out = np.zeros(7)
     _lib.load().ccm_pose_from_mat4f(_lib.ptr(T), _lib.ptr(out))

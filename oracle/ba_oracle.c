@@ -542,3 +542,110 @@ int orc_ba_reduced_system(const orc_ba_problem* pb, double huber_delta, double l
     ba_free(s);
     return P;
 }
+
+/* ---------------------------------------------------------------- F2: pose-only optimisation
+ * Optimizer::PoseOptimizationClient (src/Optimizer.cpp:215-347): one free pose, unary
+ * EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.cpp:266-296), Huber sqrt(5.991), four rounds of
+ * optimize(10) each restarted from the frame's initial pose, chi2 > 5.991 (compared in float) relabels
+ * outliers after every round, the kernel is dropped after the third round.  No marginalised vertex, so
+ * BlockSolver solves the 6x6 system directly (LinearSolverDense, Eigen LDLT). */
+static int chol6_solve(const double* H, const double* b, double* x)
+{
+    double L[36];
+    memcpy(L, H, sizeof L);
+    if (!chol_factor(L, 6)) return 0;
+    memcpy(x, b, 6 * sizeof(double));
+    chol_solve(L, 6, x);
+    return 1;
+}
+
+int orc_pose_optimize(double* pose7, const double* intr4, int n, const double* pts, const double* obs,
+                      const double* info, uint8_t* outlier, int* n_inliers)
+{
+    *n_inliers = 0;
+    for (int i = 0; i < n; i++) outlier[i] = 0;
+    if (n < 3) return 0;                                           /* :296-297 */
+    double pose0[7]; memcpy(pose0, pose7, sizeof pose0);
+    double* err = (double*)calloc(2 * (size_t)n, sizeof(double));
+    const double delta = sqrt(5.991);
+    int nBadEdges = 0;
+    for (int round = 0; round < 4; round++) {
+        const int robust = round <= 2;                             /* kernel removed at the end of it == 2 */
+        memcpy(pose7, pose0, sizeof pose0);                        /* :309 */
+        double lambda = 0, ni = 2; int nBad = 0;
+        for (int it = 0; it < 10; it++) {
+            double R[9]; quat_to_R(pose7, R);
+            double H[36], b[6], cur = 0;
+            memset(H, 0, sizeof H); memset(b, 0, sizeof b);
+            int nact = 0;
+            for (int e = 0; e < n; e++) {
+                if (outlier[e]) continue;
+                nact++;
+                double A[6], B[12];
+                edge_eval(R, pose7 + 4, intr4, pts + 3 * e, obs + 2 * e, err + 2 * e, A, B, 0);
+                const double c2 = info[e] * (err[2 * e] * err[2 * e] + err[2 * e + 1] * err[2 * e + 1]);
+                double r0 = c2, r1 = 1.;
+                if (robust) huber(c2, delta, &r0, &r1);
+                cur += r0;
+                const double w = r1 * info[e], g0 = -info[e] * err[2 * e] * r1, g1 = -info[e] * err[2 * e + 1] * r1;
+                for (int i = 0; i < 6; i++) {
+                    b[i] += B[i] * g0 + B[6 + i] * g1;
+                    for (int j = 0; j < 6; j++) H[i * 6 + j] += w * (B[i] * B[j] + B[6 + i] * B[6 + j]);
+                }
+            }
+            if (nact == 0) break;                                  /* nothing active: g2o optimises nothing */
+            const double ini = cur;
+            if (it == 0) {
+                double md = 0;
+                for (int j = 0; j < 6; j++) md = fmax(md, fabs(H[7 * j]));
+                lambda = 1e-5 * md; ni = 2; nBad = 0;
+            }
+            double rho = 0; int qmax = 0;
+            do {
+                double save[7]; memcpy(save, pose7, sizeof save);
+                double Hl[36], x[6] = { 0, 0, 0, 0, 0, 0 };
+                memcpy(Hl, H, sizeof Hl);
+                for (int j = 0; j < 6; j++) Hl[7 * j] += lambda;
+                const int ok2 = chol6_solve(Hl, b, x);
+                double temp = DBL_MAX;
+                if (ok2) {
+                    double o[7]; orc_se3_exp_mul(x, pose7, o); memcpy(pose7, o, sizeof o);
+                    double R2[9]; quat_to_R(pose7, R2);
+                    temp = 0;
+                    for (int e = 0; e < n; e++) {
+                        if (outlier[e]) continue;
+                        edge_eval(R2, pose7 + 4, intr4, pts + 3 * e, obs + 2 * e, err + 2 * e, 0, 0, 0);
+                        const double c2 = info[e] * (err[2 * e] * err[2 * e] + err[2 * e + 1] * err[2 * e + 1]);
+                        double r0 = c2, r1;
+                        if (robust) huber(c2, delta, &r0, &r1);
+                        temp += r0;
+                    }
+                }
+                double scale = 1e-3;
+                for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                rho = ok2 ? (cur - temp) / scale : -1.0;
+                if (rho > 0 && isfinite(temp)) {
+                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha); ni = 2; cur = temp;
+                } else { lambda *= ni; ni *= 2; memcpy(pose7, save, sizeof save); }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (qmax == 10 || rho == 0) break;
+            if ((ini - cur) * 1e3 < ini) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        /* classification (:313-338): inactive edges get a fresh error, active ones keep the last computed one */
+        double R[9]; quat_to_R(pose7, R);
+        nBadEdges = 0;
+        for (int e = 0; e < n; e++) {
+            if (outlier[e]) edge_eval(R, pose7 + 4, intr4, pts + 3 * e, obs + 2 * e, err + 2 * e, 0, 0, 0);
+            const float chi2 = (float)(info[e] * (err[2 * e] * err[2 * e] + err[2 * e + 1] * err[2 * e + 1]));
+            if (chi2 > 5.991f) { outlier[e] = 1; nBadEdges++; } else outlier[e] = 0;
+        }
+        if (n < 10) break;                                         /* :340-341 */
+    }
+    free(err);
+    *n_inliers = n - nBadEdges;
+    return 0;
+}

@@ -75,6 +75,9 @@ void orc_ba_edge(const double* pose7, const double* intr4, const double* pt3, co
 void orc_se3_exp_mul(const double* delta6, const double* pose7_in, double* pose7_out);
 void orc_pose_from_mat4f(const float* T16, double* pose7);
 void orc_pose_to_mat4f(const double* pose7, float* T16);
+/* F2: Optimizer::PoseOptimizationClient for one frame */
+int  orc_pose_optimize(double* pose7, const double* intr4, int n, const double* pts, const double* obs,
+                       const double* info, uint8_t* outlier, int* n_inliers);
 /* One linearisation at the current state: dense reduced system for checks.
  * Hschur (6P x 6P, P = free poses, row-major, full symmetric) and bschur; returns P. */
 int  orc_ba_reduced_system(const orc_ba_problem*, double huber_delta, double lambda,

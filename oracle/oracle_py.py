@@ -199,3 +199,12 @@ def ba_reduced_system(g, huber_delta, lam):
     P = lib().orc_ba_reduced_system(C.byref(pb), C.c_double(huber_delta), C.c_double(lam), _p(H), _p(b), _p(fi))
     assert P == nfree
     return H, b, fi
+
+
+def pose_optimize(pose7, intr4, pts, obs, info):
+    pose = np.ascontiguousarray(pose7, "f8").copy()
+    a = [np.ascontiguousarray(v, "f8") for v in (intr4, pts, obs, info)]
+    n = len(a[3])
+    outl = np.zeros(max(n, 1), np.uint8); ninl = C.c_int(0)
+    lib().orc_pose_optimize(_p(pose), _p(a[0]), n, _p(a[1]), _p(a[2]), _p(a[3]), _p(outl), C.byref(ninl))
+    return pose, outl[:n].copy(), ninl.value

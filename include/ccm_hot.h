@@ -173,6 +173,33 @@ int ccm_match_bow(ccm_ctx*, const ccm_bow_options*,
                   const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2,
                   const float* angle2, int n2, int32_t* match12);
 
+/* Windowed matchers.  A frame's undistorted keypoints with its 75x48 feature grid
+ * (Frame::AssignFeaturesToGrid, src/Frame.cpp:103-118; FRAME_GRID_COLS/ROWS include/cslam/Frame.h:51-52). */
+typedef struct {
+    int n;                         /* Frame::N */
+    const float* kp_x; const float* kp_y; const int32_t* kp_octave;   /* mvKeysUn */
+    const uint8_t* desc;           /* mDescriptors [n][32] */
+    float min_x, min_y;            /* mnMinX, mnMinY */
+    float inv_w, inv_h;            /* mfGridElementWidthInv, mfGridElementHeightInv */
+    int grid_cols, grid_rows;      /* 75, 48 */
+} ccm_frame_grid;
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cpp:200-253) for nq queries at once, with the
+ * Hamming distance of each returned feature to the query's descriptor.  Per query up to `cap` entries, in
+ * the order the reference returns them; cand_n[q] is the true count (CCM_E_CAPACITY if any exceeds cap).
+ * r < 0 skips a query. */
+int ccm_window_candidates(ccm_ctx*, const ccm_frame_grid*, int nq, const float* qx, const float* qy, const float* qr,
+                          const int32_t* min_level, const int32_t* max_level, const uint8_t* qdesc, int cap,
+                          int32_t* cand_idx, int32_t* cand_dist, int32_t* cand_n);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<mpptr>&, th) (cslam/src/ORBmatcher.cpp:71-148), the matcher
+ * of TrackLocalMap.  Per map point: in_view = mbTrackInView && !isBad, level = mnTrackScaleLevel, view_cos =
+ * mTrackViewCos, proj = mTrackProjX/Y, its descriptor, has_obs = Observations() > 0.  occupied[i] (in/out): feature i
+ * already holds a map point with observations.  match[i] = index of the map point newly assigned to feature i or
+ * -1.  Returns nmatches. */
+int ccm_search_by_projection(ccm_ctx*, const ccm_frame_grid*, const float* scale_factors, int n_mp, const uint8_t* in_view,
+                             const int32_t* level, const float* view_cos, const float* proj_x, const float* proj_y,
+                             const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied, float th, float nnratio,
+                             int32_t* match);
+
 /* ---------------------------------------------------------------- optimizer
  * The 6-DoF pose / 3-DoF point reprojection BA that Optimizer::BundleAdjustmentClient
  * (src/Optimizer.cpp:32-212), LocalBundleAdjustmentClient (:349-644) and

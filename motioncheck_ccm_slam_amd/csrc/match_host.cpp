@@ -11,7 +11,10 @@ void match_launch_bf(hipStream_t, const uint8_t* q, long long q_pair_bytes, cons
 void match_launch_ranges(hipStream_t, const uint8_t* d1, const uint8_t* d2, const int* order2, const int* start,
                          const int* len, const long long* off, int n1, unsigned short* dist);
 
+struct WindowBufs;
+void match_window_free(WindowBufs*);
 struct MatchState {
+    WindowBufs* win = nullptr;                  // windowed matchers
     DevBuf q, t, nqn, ntn, bi, bd, sd;          // brute force staging
     DevBuf part_best, part_second;              // per-split partial results
     DevBuf d1, d2, order2, start, len, off, dist; // BoW staging
@@ -21,6 +24,7 @@ void match_state_free(MatchState* s)
     if (!s) return;
     DevBuf* all[] = { &s->q, &s->t, &s->nqn, &s->ntn, &s->bi, &s->bd, &s->sd, &s->d1, &s->d2, &s->order2, &s->start, &s->len, &s->off, &s->dist, &s->part_best, &s->part_second };
     for (DevBuf* b : all) b->release();
+    match_window_free(s->win);
     delete s;
 }
 
@@ -211,6 +215,146 @@ int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, co
         for (int i = 0; i < HISTO; i++) {
             if (i == i1 || i == i2 || i == i3) continue;
             for (int idx : rot[i]) { match12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// F1: windowed matching.  The GPU enumerates, for every query, the features inside its
+// search window with their Hamming distances (k_window_candidates); the sequential acceptance of each
+// matcher stays on the host in the reference's visiting order.
+struct WinGrid {
+    int n, cols, rows; float min_x, min_y, inv_w, inv_h;
+    const float* kx; const float* ky; const int* oct; const uint8_t* desc; const int* cell_first; const int* cell_items;
+};
+void match_launch_window(hipStream_t, const WinGrid&, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
+                         const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn);
+
+struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn; };
+
+static int window_candidates(ccm_ctx* c, const ccm_frame_grid* f, int nq, const float* qx, const float* qy, const float* qr,
+                             const int32_t* minl, const int32_t* maxl, const uint8_t* qdesc, int cap,
+                             std::vector<int32_t>& ci, std::vector<int32_t>& cd, std::vector<int32_t>& cn)
+{
+    if (!c->match) c->match = new MatchState();
+    if (!c->match->win) c->match->win = new WindowBufs();
+    WindowBufs& W = *c->match->win;
+    const int n = f->n, cells = f->grid_cols * f->grid_rows;
+    // Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cpp:103-118, 255-266): mGrid[x][y], features in index order
+    std::vector<int> cell(n), first(cells + 1, 0), items(std::max(n, 1));
+    for (int i = 0; i < n; i++) {
+        const int px = (int)std::round((f->kp_x[i] - f->min_x) * f->inv_w), py = (int)std::round((f->kp_y[i] - f->min_y) * f->inv_h);
+        cell[i] = (px < 0 || px >= f->grid_cols || py < 0 || py >= f->grid_rows) ? -1 : px * f->grid_rows + py;
+        if (cell[i] >= 0) first[cell[i] + 1]++;
+    }
+    for (int k = 0; k < cells; k++) first[k + 1] += first[k];
+    { std::vector<int> fill(first.begin(), first.end() - 1); for (int i = 0; i < n; i++) if (cell[i] >= 0) items[fill[cell[i]]++] = i; }
+    hipStream_t st = c->stream;
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        CCM_RESERVE(c, b, std::max<size_t>(bytes, 16));
+        if (bytes) CCM_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+        return CCM_OK;
+    };
+    int rc;
+    if ((rc = up(W.kx, f->kp_x, (size_t)n * 4)) || (rc = up(W.ky, f->kp_y, (size_t)n * 4)) || (rc = up(W.oct, f->kp_octave, (size_t)n * 4)) ||
+        (rc = up(W.desc, f->desc, (size_t)n * 32)) || (rc = up(W.cfirst, first.data(), first.size() * 4)) ||
+        (rc = up(W.citems, items.data(), (size_t)n * 4)) || (rc = up(W.qx, qx, (size_t)nq * 4)) || (rc = up(W.qy, qy, (size_t)nq * 4)) ||
+        (rc = up(W.qr, qr, (size_t)nq * 4)) || (rc = up(W.minl, minl, (size_t)nq * 4)) || (rc = up(W.maxl, maxl, (size_t)nq * 4)) ||
+        (rc = up(W.qdesc, qdesc, (size_t)nq * 32)))
+        return rc;
+    CCM_RESERVE(c, W.ci, (size_t)nq * cap * 4); CCM_RESERVE(c, W.cd, (size_t)nq * cap * 4); CCM_RESERVE(c, W.cn, (size_t)nq * 4);
+    WinGrid G{ n, f->grid_cols, f->grid_rows, f->min_x, f->min_y, f->inv_w, f->inv_h, W.kx.as<float>(), W.ky.as<float>(), W.oct.as<int>(),
+               W.desc.as<uint8_t>(), W.cfirst.as<int>(), W.citems.as<int>() };
+    match_launch_window(st, G, nq, W.qx.as<float>(), W.qy.as<float>(), W.qr.as<float>(), W.minl.as<int>(), W.maxl.as<int>(),
+                        W.qdesc.as<uint8_t>(), cap, W.ci.as<int>(), W.cd.as<int>(), W.cn.as<int>());
+    CCM_HIP(c, hipGetLastError());
+    ci.resize((size_t)nq * cap); cd.resize((size_t)nq * cap); cn.resize(nq);
+    CCM_HIP(c, hipMemcpyAsync(ci.data(), W.ci.p, ci.size() * 4, hipMemcpyDeviceToHost, st));
+    CCM_HIP(c, hipMemcpyAsync(cd.data(), W.cd.p, cd.size() * 4, hipMemcpyDeviceToHost, st));
+    CCM_HIP(c, hipMemcpyAsync(cn.data(), W.cn.p, cn.size() * 4, hipMemcpyDeviceToHost, st));
+    CCM_HIP(c, hipStreamSynchronize(st));
+    return CCM_OK;
+}
+
+void match_window_free(WindowBufs* w)
+{
+    if (!w) return;
+    DevBuf* all[] = { &w->kx, &w->ky, &w->oct, &w->desc, &w->cfirst, &w->citems, &w->qx, &w->qy, &w->qr, &w->minl, &w->maxl, &w->qdesc, &w->ci, &w->cd, &w->cn };
+    for (DevBuf* b : all) b->release();
+    delete w;
+}
+
+extern "C" {
+
+int ccm_window_candidates(ccm_ctx* c, const ccm_frame_grid* f, int nq, const float* qx, const float* qy, const float* qr,
+                          const int32_t* min_level, const int32_t* max_level, const uint8_t* qdesc, int cap,
+                          int32_t* cand_idx, int32_t* cand_dist, int32_t* cand_n)
+{
+    if (!c || !f) return CCM_E_ARG;
+    if (nq == 0) return CCM_OK;
+    if (nq < 0 || cap < 1 || f->n < 0 || f->grid_cols < 1 || f->grid_rows < 1 || !qx || !qy || !qr || !min_level || !max_level || !qdesc ||
+        !cand_idx || !cand_dist || !cand_n || (f->n > 0 && (!f->kp_x || !f->kp_y || !f->kp_octave || !f->desc)))
+        return ccm_fail(c, CCM_E_ARG, "bad window-search arguments");
+    CCM_HIP(c, hipSetDevice(c->device));
+    std::vector<int32_t> ci, cd, cn;
+    int rc = window_candidates(c, f, nq, qx, qy, qr, min_level, max_level, qdesc, cap, ci, cd, cn);
+    if (rc) return rc;
+    std::memcpy(cand_idx, ci.data(), ci.size() * 4); std::memcpy(cand_dist, cd.data(), cd.size() * 4); std::memcpy(cand_n, cn.data(), cn.size() * 4);
+    for (int q = 0; q < nq; q++) if (cn[q] > cap) return ccm_fail(c, CCM_E_CAPACITY, "query %d has %d candidates, cap %d", q, cn[q], cap);
+    return CCM_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<mpptr>&, th), ORBmatcher.cpp:71-148
+int ccm_search_by_projection(ccm_ctx* c, const ccm_frame_grid* f, const float* scale_factors, int n_mp, const uint8_t* in_view,
+                             const int32_t* level, const float* view_cos, const float* proj_x, const float* proj_y,
+                             const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied, float th, float nnratio,
+                             int32_t* match)
+{
+    if (!c || !f) return CCM_E_ARG;
+    if (f->n < 0 || n_mp < 0 || (f->n > 0 && (!match || !occupied)) ||
+        (n_mp > 0 && (!scale_factors || !in_view || !level || !view_cos || !proj_x || !proj_y || !mp_desc || !mp_has_obs)))
+        return ccm_fail(c, CCM_E_ARG, "bad SearchByProjection arguments");
+    for (int i = 0; i < f->n; i++) match[i] = -1;
+    if (n_mp == 0 || f->n == 0) return 0;
+    CCM_HIP(c, hipSetDevice(c->device));
+    const bool bFactor = th != 1.0;
+    std::vector<float> qr(n_mp); std::vector<int32_t> minl(n_mp), maxl(n_mp);
+    for (int m = 0; m < n_mp; m++) {
+        if (!in_view[m]) { qr[m] = -1.f; minl[m] = 0; maxl[m] = 0; continue; }
+        float r = view_cos[m] > 0.998 ? 2.5f : 4.0f;                          // RadiusByViewingCos :150-156
+        if (bFactor) r *= th;
+        qr[m] = r * scale_factors[level[m]];
+        minl[m] = level[m] - 1; maxl[m] = level[m];
+    }
+    int cap = 64;
+    std::vector<int32_t> ci, cd, cn;
+    for (;;) {
+        int rc = window_candidates(c, f, n_mp, proj_x, proj_y, qr.data(), minl.data(), maxl.data(), mp_desc, cap, ci, cd, cn);
+        if (rc) return rc;
+        int mx = 0;
+        for (int v : cn) mx = std::max(mx, v);
+        if (mx <= cap) break;
+        cap = mx;                                                              // rare: a denser window than expected
+    }
+    int nmatches = 0;
+    for (int m = 0; m < n_mp; m++) {
+        if (!in_view[m] || cn[m] == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < cn[m]; k++) {
+            const int idx = ci[(size_t)m * cap + k];
+            if (occupied[idx]) continue;                                       // mvpMapPoints[idx] with Observations() > 0
+            const int dist = cd[(size_t)m * cap + k];
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = f->kp_octave[idx]; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = f->kp_octave[idx]; bestDist2 = dist; }
+        }
+        if (bestDist <= 100) {                                                 // TH_HIGH
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            match[bestIdx] = m;
+            occupied[bestIdx] = mp_has_obs[m];
+            nmatches++;
         }
     }
     return nmatches;

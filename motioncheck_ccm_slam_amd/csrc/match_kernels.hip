@@ -144,6 +144,71 @@ __global__ __launch_bounds__(256) void k_hamming_ranges(
     }
 }
 
+// Frame::GetFeaturesInArea (src/Frame.cpp:200-253) + the DescriptorDistance calls of the windowed matchers
+// (SearchByProjection / Fuse / SearchBySim3 ..., cslam/src/ORBmatcher.cpp:71-148 and following): one wave per
+// query walks the grid cells of its window in the reference's order (ix outer, iy inner, cell content in
+// feature-index order), applies the level and |dx|,|dy| < r tests in float exactly as written there, and emits
+// (feature index, Hamming distance) in that order through ballot compaction.
+struct WinGrid {
+    int n, cols, rows;
+    float min_x, min_y, inv_w, inv_h;
+    const float* kx; const float* ky; const int* oct; const uint8_t* desc;
+    const int* cell_first; const int* cell_items;
+};
+__global__ __launch_bounds__(256) void k_window_candidates(WinGrid G, int nq, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                           const float* __restrict__ qr, const int* __restrict__ min_level,
+                                                           const int* __restrict__ max_level, const uint8_t* __restrict__ qdesc, int cap,
+                                                           int* __restrict__ cand_idx, int* __restrict__ cand_dist, int* __restrict__ cand_n)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const float x = qx[q], y = qy[q], r = qr[q];
+    const int minL = min_level[q], maxL = max_level[q];
+    int n = 0;
+    if (r >= 0.f) {                                        // r < 0 marks a query that is not searched
+        const int nMinCellX = max(0, (int)floorf((x - G.min_x - r) * G.inv_w));
+        const int nMaxCellX = min(G.cols - 1, (int)ceilf((x - G.min_x + r) * G.inv_w));
+        const int nMinCellY = max(0, (int)floorf((y - G.min_y - r) * G.inv_h));
+        const int nMaxCellY = min(G.rows - 1, (int)ceilf((y - G.min_y + r) * G.inv_h));
+        if (nMinCellX < G.cols && nMaxCellX >= 0 && nMinCellY < G.rows && nMaxCellY >= 0) {
+            const bool check = (minL > 0) || (maxL >= 0);
+            const uint4* qd = reinterpret_cast<const uint4*>(qdesc) + 2 * (long long)q;
+            const uint4 a0 = qd[0], a1 = qd[1];
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                // the cells (ix, nMinCellY..nMaxCellY) are adjacent in the CSR (column-major grid): one contiguous item range
+                const int k0 = G.cell_first[ix * G.rows + nMinCellY], k1 = G.cell_first[ix * G.rows + nMaxCellY + 1];
+                for (int base = k0; base < k1; base += 64) {
+                    const int k = base + lane;
+                    bool keep = false; int i = 0;
+                    if (k < k1) {
+                        i = G.cell_items[k];
+                        const int o = G.oct[i];
+                        keep = !(check && (o < minL || (maxL >= 0 && o > maxL)));
+                        const float dx = G.kx[i] - x, dy = G.ky[i] - y;
+                        keep = keep && fabsf(dx) < r && fabsf(dy) < r;
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) {
+                        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < cap) {
+                            const uint4* b = reinterpret_cast<const uint4*>(G.desc) + 2 * (long long)i;
+                            cand_idx[(long long)q * cap + pos] = i;
+                            cand_dist[(long long)q * cap + pos] = ham256(a0, a1, b[0], b[1]);
+                        }
+                    }
+                    n += __popcll(m);
+                }
+            }
+        }
+    }
+    if (lane == 0) cand_n[q] = n;
+}
+void match_launch_window(hipStream_t s, const WinGrid& G, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
+                         const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn)
+{
+    hipLaunchKernelGGL(k_window_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, G, nq, qx, qy, qr, minl, maxl, qdesc, cap, ci, cd, cn);
+}
+
 // variant: 0 = 512 threads x 2 queries, 1 = 256 x 4, 2 = 1024 x 1 (tuning knob, CCM_BF_VARIANT)
 void match_launch_bf(hipStream_t s, const uint8_t* q, long long q_pair_bytes, const uint8_t* t, long long t_pair_bytes,
                      int nq, int nt, int n_pairs, const int* nq_n, const int* nt_n, int n_split, int variant,

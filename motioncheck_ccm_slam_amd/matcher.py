@@ -72,3 +72,57 @@ class ORBmatcher:
                                                   _lib.ptr(valid1), _lib.ptr(a1), n1, _lib.ptr(d2), _lib.ptr(node2),
                                                   _lib.ptr(v2), _lib.ptr(a2), n2, _lib.ptr(m)))
         return n, m
+
+
+FRAME_GRID_COLS, FRAME_GRID_ROWS = 75, 48        # include/cslam/Frame.h:51-52
+
+
+class FrameGridView:
+    """What the windowed matchers need from a `Frame`: undistorted keypoints, descriptors and the feature grid
+    parameters computed in the Frame constructor (src/Frame.cpp:80-88)."""
+
+    def __init__(self, kp_x, kp_y, kp_octave, desc, min_x=0.0, max_x=752.0, min_y=0.0, max_y=480.0):
+        self.kx = np.ascontiguousarray(kp_x, "f4"); self.ky = np.ascontiguousarray(kp_y, "f4")
+        self.oct = np.ascontiguousarray(kp_octave, "i4"); self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.min_x = np.float32(min_x); self.min_y = np.float32(min_y)
+        self.inv_w = np.float32(FRAME_GRID_COLS) / np.float32(np.float32(max_x) - np.float32(min_x))
+        self.inv_h = np.float32(FRAME_GRID_ROWS) / np.float32(np.float32(max_y) - np.float32(min_y))
+
+    def struct(self):
+        p = _lib.ptr
+        return _lib.FrameGrid(len(self.kx), p(self.kx), p(self.ky), p(self.oct), p(self.desc), float(self.min_x), float(self.min_y),
+                              float(self.inv_w), float(self.inv_h), FRAME_GRID_COLS, FRAME_GRID_ROWS)
+
+
+def _features_in_area(self, frame: FrameGridView, x, y, r, min_level, max_level, qdesc, cap=256):
+    """Frame::GetFeaturesInArea for many queries + Hamming distance to each query descriptor."""
+    x = np.ascontiguousarray(x, "f4"); y = np.ascontiguousarray(y, "f4"); r = np.ascontiguousarray(r, "f4")
+    mn = np.ascontiguousarray(min_level, "i4"); mx = np.ascontiguousarray(max_level, "i4")
+    qd = np.ascontiguousarray(qdesc, np.uint8)
+    nq = len(x)
+    ci = np.zeros((nq, cap), "i4"); cd = np.zeros((nq, cap), "i4"); cn = np.zeros(nq, "i4")
+    g = frame.struct()
+    self.ctx.check(self.lib.ccm_window_candidates(self.ctx.handle, C.byref(g), nq, _lib.ptr(x), _lib.ptr(y), _lib.ptr(r), _lib.ptr(mn),
+                                                  _lib.ptr(mx), _lib.ptr(qd), cap, _lib.ptr(ci), _lib.ptr(cd), _lib.ptr(cn)))
+    return ci, cd, cn
+
+
+def _search_by_projection(self, frame: FrameGridView, scale_factors, in_view, level, view_cos, proj_x, proj_y, mp_desc,
+                          mp_has_obs, occupied, th: float = 1.0):
+    """ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (ORBmatcher.cpp:71-148).
+    Returns (nmatches, match[feature] = map point index or -1, occupied after the call)."""
+    sf = np.ascontiguousarray(scale_factors, "f4"); iv = np.ascontiguousarray(in_view, np.uint8)
+    lv = np.ascontiguousarray(level, "i4"); vc = np.ascontiguousarray(view_cos, "f4")
+    px = np.ascontiguousarray(proj_x, "f4"); py = np.ascontiguousarray(proj_y, "f4")
+    md = np.ascontiguousarray(mp_desc, np.uint8); ho = np.ascontiguousarray(mp_has_obs, np.uint8)
+    occ = np.ascontiguousarray(occupied, np.uint8).copy()
+    match = np.full(max(len(frame.kx), 1), -1, "i4")
+    g = frame.struct()
+    n = self.ctx.check(self.lib.ccm_search_by_projection(self.ctx.handle, C.byref(g), _lib.ptr(sf), len(iv), _lib.ptr(iv), _lib.ptr(lv),
+                                                         _lib.ptr(vc), _lib.ptr(px), _lib.ptr(py), _lib.ptr(md), _lib.ptr(ho), _lib.ptr(occ),
+                                                         C.c_float(th), C.c_float(self.mfNNratio), _lib.ptr(match)))
+    return n, match[:len(frame.kx)], occ
+
+
+ORBmatcher.FeaturesInArea = _features_in_area
+ORBmatcher.SearchByProjection = _search_by_projection

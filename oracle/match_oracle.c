@@ -130,3 +130,105 @@ int orc_match_bow(float nnratio, int check_ori, int th, int strict_th,
     free(f1); free(f2); free(taken2); free(hist);
     return nmatches;
 }
+
+/* ---------------------------------------------------------------- F1: windowed matching
+ * Frame grid: AssignFeaturesToGrid / PosInGrid (src/Frame.cpp:103-118, 255-266), GetFeaturesInArea
+ * (src/Frame.cpp:200-253), and ORBmatcher::SearchByProjection(Frame&, vector<mpptr>&, th)
+ * (cslam/src/ORBmatcher.cpp:71-148). */
+typedef struct { int n, cols, rows; float min_x, min_y, inv_w, inv_h; int* first; int* items; } orc_grid;
+
+static orc_grid* grid_build(int n, const float* kx, const float* ky, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows)
+{
+    orc_grid* g = (orc_grid*)calloc(1, sizeof *g);
+    g->n = n; g->cols = cols; g->rows = rows; g->min_x = min_x; g->min_y = min_y; g->inv_w = inv_w; g->inv_h = inv_h;
+    g->first = (int*)calloc((size_t)cols * rows + 1, sizeof(int));
+    g->items = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int* cell = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        const int px = (int)roundf((kx[i] - min_x) * inv_w), py = (int)roundf((ky[i] - min_y) * inv_h);
+        cell[i] = (px < 0 || px >= cols || py < 0 || py >= rows) ? -1 : px * rows + py;      /* mGrid[x][y] */
+        if (cell[i] >= 0) g->first[cell[i] + 1]++;
+    }
+    for (int c = 0; c < cols * rows; c++) g->first[c + 1] += g->first[c];
+    int* fill = (int*)malloc(sizeof(int) * ((size_t)cols * rows + 1));
+    memcpy(fill, g->first, sizeof(int) * ((size_t)cols * rows + 1));
+    for (int i = 0; i < n; i++) if (cell[i] >= 0) g->items[fill[cell[i]]++] = i;            /* push_back in index order */
+    free(cell); free(fill);
+    return g;
+}
+static void grid_free(orc_grid* g) { free(g->first); free(g->items); free(g); }
+
+static int features_in_area(const orc_grid* g, const float* kx, const float* ky, const int32_t* oct,
+                            float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap)
+{
+    int n = 0;
+    const int nMinCellX = (int)floorf((x - g->min_x - r) * g->inv_w) > 0 ? (int)floorf((x - g->min_x - r) * g->inv_w) : 0;
+    if (nMinCellX >= g->cols) return 0;
+    int nMaxCellX = (int)ceilf((x - g->min_x + r) * g->inv_w); if (nMaxCellX > g->cols - 1) nMaxCellX = g->cols - 1;
+    if (nMaxCellX < 0) return 0;
+    const int nMinCellY = (int)floorf((y - g->min_y - r) * g->inv_h) > 0 ? (int)floorf((y - g->min_y - r) * g->inv_h) : 0;
+    if (nMinCellY >= g->rows) return 0;
+    int nMaxCellY = (int)ceilf((y - g->min_y + r) * g->inv_h); if (nMaxCellY > g->rows - 1) nMaxCellY = g->rows - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * g->rows + iy;
+            for (int k = g->first[c]; k < g->first[c + 1]; k++) {
+                const int i = g->items[k];
+                if (bCheckLevels) {
+                    if (oct[i] < minLevel) continue;
+                    if (maxLevel >= 0 && oct[i] > maxLevel) continue;
+                }
+                const float dx = kx[i] - x, dy = ky[i] - y;
+                if (fabsf(dx) < r && fabsf(dy) < r) { if (n < cap) out[n] = i; n++; }
+            }
+        }
+    return n;
+}
+
+int orc_features_in_area(int n, const float* kx, const float* ky, const int32_t* oct, float min_x, float min_y, float inv_w, float inv_h,
+                         int cols, int rows, float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap)
+{
+    orc_grid* g = grid_build(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows);
+    const int m = features_in_area(g, kx, ky, oct, x, y, r, minLevel, maxLevel, out, cap);
+    grid_free(g);
+    return m;
+}
+
+int orc_search_by_projection(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
+                             float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                             int n_mp, const uint8_t* in_view, const int32_t* level, const float* view_cos, const float* proj_x,
+                             const float* proj_y, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                             uint8_t* occupied, float th, float nnratio, int32_t* match)
+{
+    orc_grid* g = grid_build(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) match[i] = -1;
+    int nmatches = 0;
+    const int bFactor = th != 1.0;
+    for (int m = 0; m < n_mp; m++) {
+        if (!in_view[m]) continue;                                            /* mbTrackInView, isBad */
+        const int lvl = level[m];
+        float r = view_cos[m] > 0.998 ? 2.5f : 4.0f;                          /* RadiusByViewingCos :150-156 */
+        if (bFactor) r *= th;
+        const int nc = features_in_area(g, kx, ky, oct, proj_x[m], proj_y[m], r * scale_factors[lvl], lvl - 1, lvl, cand, n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            if (occupied[idx]) continue;                                       /* mvpMapPoints[idx] with Observations()>0 */
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)m, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct[idx]; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = oct[idx]; bestDist2 = dist; }
+        }
+        if (bestDist <= 100) {                                                 /* TH_HIGH */
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            match[bestIdx] = m;                                                /* F.mvpMapPoints[bestIdx] = pMP */
+            occupied[bestIdx] = mp_has_obs[m];
+            nmatches++;
+        }
+    }
+    free(cand); grid_free(g);
+    return nmatches;
+}

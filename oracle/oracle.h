@@ -60,6 +60,15 @@ int  orc_match_bow(float nnratio, int check_ori, int th, int strict_th,
                    const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2, const float* angle2, int n2,
                    int32_t* match12);
 
+/* F1: Frame::GetFeaturesInArea and ORBmatcher::SearchByProjection(Frame&, vector<mpptr>&, th) */
+int  orc_features_in_area(int n, const float* kx, const float* ky, const int32_t* oct, float min_x, float min_y, float inv_w, float inv_h,
+                          int cols, int rows, float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap);
+int  orc_search_by_projection(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
+                              float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                              int n_mp, const uint8_t* in_view, const int32_t* level, const float* view_cos, const float* proj_x,
+                              const float* proj_y, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                              uint8_t* occupied, float th, float nnratio, int32_t* match);
+
 /* ---- bundle adjustment ---- */
 typedef struct {
     int n_poses; double* poses; const uint8_t* fixed; const double* intr;

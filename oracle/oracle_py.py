@@ -208,3 +208,24 @@ def pose_optimize(pose7, intr4, pts, obs, info):
     outl = np.zeros(max(n, 1), np.uint8); ninl = C.c_int(0)
     lib().orc_pose_optimize(_p(pose), _p(a[0]), n, _p(a[1]), _p(a[2]), _p(a[3]), _p(outl), C.byref(ninl))
     return pose, outl[:n].copy(), ninl.value
+
+
+def features_in_area(kx, ky, octv, min_x, min_y, inv_w, inv_h, x, y, r, min_level, max_level, cols=75, rows=48):
+    kx = np.ascontiguousarray(kx, "f4"); ky = np.ascontiguousarray(ky, "f4"); octv = np.ascontiguousarray(octv, "i4")
+    out = np.zeros(max(len(kx), 1), "i4")
+    n = lib().orc_features_in_area(len(kx), _p(kx), _p(ky), _p(octv), C.c_float(min_x), C.c_float(min_y), C.c_float(inv_w), C.c_float(inv_h),
+                                   cols, rows, C.c_float(x), C.c_float(y), C.c_float(r), int(min_level), int(max_level), _p(out), len(out))
+    return out[:n].copy()
+
+
+def search_by_projection(kx, ky, octv, desc, min_x, min_y, inv_w, inv_h, scale_factors, in_view, level, view_cos, proj_x, proj_y,
+                         mp_desc, mp_has_obs, occupied, th, nnratio, cols=75, rows=48):
+    a = lambda v, t: np.ascontiguousarray(v, t)
+    kx = a(kx, "f4"); ky = a(ky, "f4"); octv = a(octv, "i4"); desc = a(desc, np.uint8); sf = a(scale_factors, "f4")
+    iv = a(in_view, np.uint8); lv = a(level, "i4"); vc = a(view_cos, "f4"); px = a(proj_x, "f4"); py = a(proj_y, "f4")
+    md = a(mp_desc, np.uint8); ho = a(mp_has_obs, np.uint8); occ = a(occupied, np.uint8).copy()
+    match = np.full(max(len(kx), 1), -1, "i4")
+    n = lib().orc_search_by_projection(len(kx), _p(kx), _p(ky), _p(octv), _p(desc), C.c_float(min_x), C.c_float(min_y), C.c_float(inv_w),
+                                       C.c_float(inv_h), cols, rows, _p(sf), len(iv), _p(iv), _p(lv), _p(vc), _p(px), _p(py), _p(md), _p(ho),
+                                       _p(occ), C.c_float(th), C.c_float(nnratio), _p(match))
+    return n, match[:len(kx)].copy(), occ

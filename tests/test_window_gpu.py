@@ -1,0 +1,68 @@
+"""Windowed matching: batched Frame::GetFeaturesInArea with distances and
+ORBmatcher::SearchByProjection(Frame&, map points, th) on the GPU vs the CPU oracle.  The frame is a real
+extraction of a synthetic image; the map points are its own features re-projected with noise."""
+import numpy as np
+import pytest
+
+from motioncheck_ccm_slam_amd import synth
+from motioncheck_ccm_slam_amd.matcher import FrameGridView, ORBmatcher
+from motioncheck_ccm_slam_amd.orb import ORBextractor
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(ctx, f=0):
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+    kps, desc = ex(synth.frame(f))
+    return FrameGridView(kps["x"], kps["y"], kps["octave"], desc), ex.GetScaleFactors(), kps, desc
+
+
+def test_features_in_area(ctx, oracle):
+    fr, sf, kps, desc = _frame(ctx)
+    m = ORBmatcher(0.8, ctx=ctx)
+    rng = np.random.default_rng(0)
+    nq = 400
+    x = rng.uniform(-30, 780, nq).astype("f4"); y = rng.uniform(-30, 510, nq).astype("f4")
+    r = rng.choice([2.5, 4.0, 10.0, 25.0, 60.0], nq).astype("f4")
+    mn = rng.integers(-1, 6, nq); mx = np.where(rng.random(nq) < 0.3, -1, mn + rng.integers(0, 3, nq))
+    qd = desc[rng.integers(0, len(desc), nq)]
+    r[5] = -1.0                                                    # skipped query
+    ci, cd, cn = m.FeaturesInArea(fr, x, y, r, mn, mx, qd, cap=1100)
+    assert cn[5] == 0
+    for q in range(nq):
+        if r[q] < 0:
+            continue
+        ref = oracle.features_in_area(fr.kx, fr.ky, fr.oct, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, x[q], y[q], r[q], mn[q], mx[q])
+        assert cn[q] == len(ref) and (ci[q, :cn[q]] == ref).all(), q
+        for k in range(0, cn[q], 7):
+            assert cd[q, k] == oracle.distance(qd[q], desc[ci[q, k]])
+    assert cn.max() > 50 and (cn == 0).sum() > 0
+
+
+@pytest.mark.parametrize("th", [1.0, 3.0])
+def test_search_by_projection(ctx, oracle, th):
+    fr, sf, kps, desc = _frame(ctx, 1)
+    n = len(fr.kx)
+    rng = np.random.default_rng(1)
+    # map points: 1500 = features of the frame (noisy projection, noisy descriptor) + 300 unrelated
+    src = rng.integers(0, n, 1200)
+    flips = np.packbits(rng.random((1200, 256)) < 0.05, axis=1, bitorder="little")
+    mp_desc = np.concatenate([desc[src] ^ flips, rng.integers(0, 256, (300, 32), dtype=np.uint8)])
+    px = np.concatenate([fr.kx[src] + rng.normal(0, 1.5, 1200), rng.uniform(0, 752, 300)]).astype("f4")
+    py = np.concatenate([fr.ky[src] + rng.normal(0, 1.5, 1200), rng.uniform(0, 480, 300)]).astype("f4")
+    level = np.concatenate([np.clip(fr.oct[src] + rng.integers(0, 2, 1200), 0, 7), rng.integers(0, 8, 300)])
+    view_cos = rng.uniform(0.99, 1.0, 1500).astype("f4")
+    in_view = rng.random(1500) < 0.9
+    has_obs = rng.random(1500) < 0.95
+    occupied = rng.random(n) < 0.2                               # features already matched by the previous tracking stage
+    m = ORBmatcher(0.8, ctx=ctx)
+    nm, match, occ = m.SearchByProjection(fr, sf, in_view, level, view_cos, px, py, mp_desc, has_obs, occupied, th)
+    rn, rmatch, rocc = oracle.search_by_projection(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, in_view, level,
+                                                   view_cos, px, py, mp_desc, has_obs, occupied, th, 0.8)
+    assert nm == rn and (match == rmatch).all() and (occ == rocc).all()
+    assert nm > 300
+    good = match >= 0
+    assert (match[good] < 1200).mean() > 0.95                   # matches go to the true correspondences
+    # nothing in view -> nothing matched
+    nm, match, _ = m.SearchByProjection(fr, sf, np.zeros(1500, bool), level, view_cos, px, py, mp_desc, has_obs, occupied, th)
+    assert nm == 0 and (match == -1).all()

@@ -200,6 +200,16 @@ int ccm_search_by_projection(ccm_ctx*, const ccm_frame_grid*, const float* scale
                              const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied, float th, float nnratio,
                              int32_t* match);
 
+/* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th) (ORBmatcher.cpp:1350-1476), the matcher of
+ * TrackWithMotionModel.  Per last-frame feature: valid = has a map point, not an outlier, and its projection (u,v)
+ * into the current frame (computed by the caller in float as :1382-1393) has positive depth and lies inside the
+ * frame bounds; last_octave, last_angle = LastFrame.mvKeys[i].octave / mvKeysUn[i].angle.  match[i2] = last-frame
+ * feature whose map point is assigned to current feature i2, or -1.  Returns nmatches. */
+int ccm_search_by_projection_frame(ccm_ctx*, const ccm_frame_grid* current, const float* cur_angle, const float* scale_factors,
+                                   int n_last, const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave,
+                                   const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied,
+                                   float th, int check_ori, int32_t* match);
+
 /* ---------------------------------------------------------------- optimizer
  * The 6-DoF pose / 3-DoF point reprojection BA that Optimizer::BundleAdjustmentClient
  * (src/Optimizer.cpp:32-212), LocalBundleAdjustmentClient (:349-644) and

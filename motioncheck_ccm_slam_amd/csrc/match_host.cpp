@@ -360,4 +360,70 @@ int ccm_search_by_projection(ccm_ctx* c, const ccm_frame_grid* f, const float* s
     return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th), ORBmatcher.cpp:1350-1476
+int ccm_search_by_projection_frame(ccm_ctx* c, const ccm_frame_grid* f, const float* cur_angle, const float* scale_factors, int n_last,
+                                   const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave, const float* last_angle,
+                                   const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied, float th, int check_ori,
+                                   int32_t* match)
+{
+    if (!c || !f) return CCM_E_ARG;
+    if (f->n < 0 || n_last < 0 || (f->n > 0 && (!match || !occupied || (check_ori && !cur_angle))) ||
+        (n_last > 0 && (!scale_factors || !valid || !u || !v || !last_octave || !mp_desc || !mp_has_obs || (check_ori && !last_angle))))
+        return ccm_fail(c, CCM_E_ARG, "bad SearchByProjection(frame, frame) arguments");
+    for (int i = 0; i < f->n; i++) match[i] = -1;
+    if (n_last == 0 || f->n == 0) return 0;
+    CCM_HIP(c, hipSetDevice(c->device));
+    std::vector<float> qr(n_last); std::vector<int32_t> minl(n_last), maxl(n_last);
+    for (int i = 0; i < n_last; i++) {
+        if (!valid[i]) { qr[i] = -1.f; minl[i] = 0; maxl[i] = 0; continue; }
+        qr[i] = th * scale_factors[last_octave[i]];                           // :1401
+        minl[i] = last_octave[i] - 1; maxl[i] = last_octave[i] + 1;           // :1405
+    }
+    int cap = 64;
+    std::vector<int32_t> ci, cd, cn;
+    for (;;) {
+        int rc = window_candidates(c, f, n_last, u, v, qr.data(), minl.data(), maxl.data(), mp_desc, cap, ci, cd, cn);
+        if (rc) return rc;
+        int mx = 0;
+        for (int k : cn) mx = std::max(mx, k);
+        if (mx <= cap) break;
+        cap = mx;
+    }
+    const int HISTO = 30;
+    std::vector<int> rot[HISTO];
+    const float factor = 1.0f / HISTO;
+    int nmatches = 0;
+    for (int i = 0; i < n_last; i++) {
+        if (!valid[i] || cn[i] == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < cn[i]; k++) {
+            const int i2 = ci[(size_t)i * cap + k];
+            if (occupied[i2]) continue;
+            const int dist = cd[(size_t)i * cap + k];
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= 100) {                                                 // TH_HIGH
+            match[bestIdx2] = i;
+            occupied[bestIdx2] = mp_has_obs[i];
+            nmatches++;
+            if (check_ori) {
+                float r = last_angle[i] - cur_angle[bestIdx2];
+                if (r < 0.0) r += 360.0f;
+                int bin = (int)std::round(r * factor);
+                if (bin == HISTO) bin = 0;
+                rot[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(rot, HISTO, i1, i2, i3);
+        for (int b = 0; b < HISTO; b++) {
+            if (b == i1 || b == i2 || b == i3) continue;
+            for (int idx : rot[b]) { match[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 }  // extern "C"

@@ -126,3 +126,21 @@ def _search_by_projection(self, frame: FrameGridView, scale_factors, in_view, le
 
 ORBmatcher.FeaturesInArea = _features_in_area
 ORBmatcher.SearchByProjection = _search_by_projection
+
+
+def _search_by_projection_frame(self, cur: FrameGridView, cur_angle, scale_factors, valid, u, v, last_octave, last_angle, mp_desc,
+                                mp_has_obs, occupied, th: float):
+    """ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th) (ORBmatcher.cpp:1350-1476)."""
+    a = np.ascontiguousarray
+    ca = a(cur_angle, "f4"); sf = a(scale_factors, "f4"); va = a(valid, np.uint8); uu = a(u, "f4"); vv = a(v, "f4")
+    lo = a(last_octave, "i4"); la = a(last_angle, "f4"); md = a(mp_desc, np.uint8); ho = a(mp_has_obs, np.uint8)
+    occ = a(occupied, np.uint8).copy()
+    match = np.full(max(len(cur.kx), 1), -1, "i4")
+    g = cur.struct()
+    p = _lib.ptr
+    n = self.ctx.check(self.lib.ccm_search_by_projection_frame(self.ctx.handle, C.byref(g), p(ca), p(sf), len(va), p(va), p(uu), p(vv), p(lo),
+                                                               p(la), p(md), p(ho), p(occ), C.c_float(th), int(self.mbCheckOrientation), p(match)))
+    return n, match[:len(cur.kx)], occ
+
+
+ORBmatcher.SearchByProjectionFrame = _search_by_projection_frame

@@ -232,3 +232,59 @@ int orc_search_by_projection(int n, const float* kx, const float* ky, const int3
     free(cand); grid_free(g);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th) (ORBmatcher.cpp:1350-1476), the matcher of
+ * TrackWithMotionModel.  valid[i]: last-frame feature i has a map point, is not an outlier, projects with
+ * positive depth inside the current frame's bounds; (u,v)[i] is that projection (the caller computes it in
+ * float exactly as :1382-1393). */
+int orc_search_by_projection_frame(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc, const float* angle,
+                                   float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                                   int n_last, const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave,
+                                   const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                   uint8_t* occupied, float th, int check_ori, int32_t* match)
+{
+    enum { HISTO = 30 };
+    orc_grid* g = grid_build(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    int32_t* hist = (int32_t*)malloc(sizeof(int32_t) * HISTO * (size_t)(n_last > 0 ? n_last : 1));
+    int32_t hn[HISTO]; memset(hn, 0, sizeof hn);
+    for (int i = 0; i < n; i++) match[i] = -1;
+    const float factor = 1.0f / HISTO;
+    int nmatches = 0;
+    for (int i = 0; i < n_last; i++) {
+        if (!valid[i]) continue;
+        const int lo = last_octave[i];
+        const float radius = th * scale_factors[lo];
+        const int nc = features_in_area(g, kx, ky, oct, u[i], v[i], radius, lo - 1, lo + 1, cand, n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            if (occupied[i2]) continue;
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= 100) {
+            match[bestIdx2] = i;
+            occupied[bestIdx2] = mp_has_obs[i];
+            nmatches++;
+            if (check_ori) {
+                float rot = last_angle[i] - angle[bestIdx2];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO) bin = 0;
+                hist[bin * (size_t)n_last + hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_ori) {
+        int32_t ind[3];
+        orc_three_maxima(hn, HISTO, ind);
+        for (int b = 0; b < HISTO; b++) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int j = 0; j < hn[b]; j++) { match[hist[b * (size_t)n_last + j]] = -1; nmatches--; }
+        }
+    }
+    free(cand); free(hist); grid_free(g);
+    return nmatches;
+}

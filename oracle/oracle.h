@@ -69,6 +69,12 @@ int  orc_search_by_projection(int n, const float* kx, const float* ky, const int
                               const float* proj_y, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
                               uint8_t* occupied, float th, float nnratio, int32_t* match);
 
+int  orc_search_by_projection_frame(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc, const float* angle,
+                                    float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                                    int n_last, const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave,
+                                    const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
+                                    uint8_t* occupied, float th, int check_ori, int32_t* match);
+
 /* ---- bundle adjustment ---- */
 typedef struct {
     int n_poses; double* poses; const uint8_t* fixed; const double* intr;

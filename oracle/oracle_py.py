@@ -229,3 +229,16 @@ def search_by_projection(kx, ky, octv, desc, min_x, min_y, inv_w, inv_h, scale_f
                                        C.c_float(inv_h), cols, rows, _p(sf), len(iv), _p(iv), _p(lv), _p(vc), _p(px), _p(py), _p(md), _p(ho),
                                        _p(occ), C.c_float(th), C.c_float(nnratio), _p(match))
     return n, match[:len(kx)].copy(), occ
+
+
+def search_by_projection_frame(kx, ky, octv, desc, angle, min_x, min_y, inv_w, inv_h, scale_factors, valid, u, v, last_octave, last_angle,
+                               mp_desc, mp_has_obs, occupied, th, check_ori, cols=75, rows=48):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    kx = a(kx, "f4"); ky = a(ky, "f4"); octv = a(octv, "i4"); desc = a(desc, np.uint8); angle = a(angle, "f4"); sf = a(scale_factors, "f4")
+    va = a(valid, np.uint8); u = a(u, "f4"); v = a(v, "f4"); lo = a(last_octave, "i4"); la = a(last_angle, "f4")
+    md = a(mp_desc, np.uint8); ho = a(mp_has_obs, np.uint8); occ = a(occupied, np.uint8).copy()
+    match = np.full(max(len(kx), 1), -1, "i4")
+    n = lib().orc_search_by_projection_frame(len(kx), _p(kx), _p(ky), _p(octv), _p(desc), _p(angle), C.c_float(min_x), C.c_float(min_y),
+                                             C.c_float(inv_w), C.c_float(inv_h), cols, rows, _p(sf), len(va), _p(va), _p(u), _p(v), _p(lo),
+                                             _p(la), _p(md), _p(ho), _p(occ), C.c_float(th), int(check_ori), _p(match))
+    return n, match[:len(kx)].copy(), occ

@@ -66,3 +66,28 @@ def test_search_by_projection(ctx, oracle, th):
     # nothing in view -> nothing matched
     nm, match, _ = m.SearchByProjection(fr, sf, np.zeros(1500, bool), level, view_cos, px, py, mp_desc, has_obs, occupied, th)
     assert nm == 0 and (match == -1).all()
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_projection_frame_to_frame(ctx, oracle, check_ori):
+    """TrackWithMotionModel's matcher: last frame = frame 2, current = the same image shifted by a few pixels."""
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+    img = synth.frame(2)
+    cur_img = np.roll(img, (3, -5), axis=(0, 1))
+    k1, d1 = ex(img); k2, d2 = ex(cur_img)
+    cur = FrameGridView(k2["x"], k2["y"], k2["octave"], d2)
+    sf = ex.GetScaleFactors()
+    rng = np.random.default_rng(4)
+    n_last = len(k1)
+    valid = rng.random(n_last) < 0.85
+    u = (k1["x"] - 5 + rng.normal(0, 1.0, n_last)).astype("f4"); v = (k1["y"] + 3 + rng.normal(0, 1.0, n_last)).astype("f4")
+    valid &= (u >= 0) & (u <= 752) & (v >= 0) & (v <= 480)
+    has_obs = rng.random(n_last) < 0.9                             # a few map points without observations: overwrites happen
+    occupied = np.zeros(len(k2), bool)
+    m = ORBmatcher(0.9, check_ori, ctx=ctx)
+    for th in (7.0, 15.0):
+        nm, match, occ = m.SearchByProjectionFrame(cur, k2["angle"], sf, valid, u, v, k1["octave"], k1["angle"], d1, has_obs, occupied, th)
+        rn, rmatch, rocc = oracle.search_by_projection_frame(cur.kx, cur.ky, cur.oct, d2, k2["angle"], cur.min_x, cur.min_y, cur.inv_w, cur.inv_h,
+                                                             sf, valid, u, v, k1["octave"], k1["angle"], d1, has_obs, occupied, th, check_ori)
+        assert nm == rn and (match == rmatch).all() and (occ == rocc).all()
+        assert nm > 200

@@ -52,7 +52,7 @@ void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int*
 void pcg_launch_minv(hipStream_t, const double* Hb, const int* diag, int nfree, double* Minv, int* bad);
 void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc);
 void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc, int first);
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int first, int parity);
 void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc);
 void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_update(hipStream_t, const BaDev&);
@@ -314,7 +314,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     const bool use_pcg = n > dense_max;
     // The PCG inner loop is three small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
-    const int pcg_chunk = 16;
+    const int pcg_chunk = 16;                     // even: the r.z slot parity is the same at the start of every chunk
     hipGraph_t pcg_graph = nullptr; hipGraphExec_t pcg_exec = nullptr;
     struct GraphGuard { hipGraph_t& g; hipGraphExec_t& e; ~GraphGuard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } graph_guard{pcg_graph, pcg_exec};
     if (use_pcg && nfree > 0) {
@@ -322,7 +322,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
             for (int k = 0; k < pcg_chunk; k++)
                 pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0);
+                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0, k & 1);
             pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
             hipError_t e1 = hipStreamEndCapture(st, &pcg_graph);
             hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec, pcg_graph, nullptr, nullptr, 0) : e1;
@@ -427,7 +427,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                                 else {
                                     for (int k = 0; k < pcg_chunk; k++)
                                         pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0);
+                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0, k & 1);
                                     pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
                                 }
                             }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ 
     if (threadIdx.x != 0) return;
     double rz = 0, bb = 0;
     for (int i = 0; i < nblk; i++) { rz += part[2 * i]; bb += part[2 * i + 1]; }
-    sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0;
+    sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0; sc[8] = rz; sc[9] = rz;
 }
 
 // Ap = A p, one workgroup per block row: thread = (entry slot 0..41, row component 0..5); the 42 slot sums of a
@@ -359,28 +359,36 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
 // residual components of its pose are recomputed locally).  Every block re-reduces p.Ap (nfree values) itself.
 #define PCG_UPD_TPB 192       // a multiple of 6: the six scalars of a pose never straddle two blocks
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __restrict__ Minv, int nfree, double* __restrict__ w,
-                                                            const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part)
+                                                            const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part,
+                                                            int parity)
 {
     __shared__ double red[256];
     __shared__ double red2[2][3];
-    double s = 0;
-    for (int i = threadIdx.x; i < nfree; i += PCG_UPD_TPB) s += pap_part[i];
-    red[threadIdx.x] = s;
-    if (threadIdx.x < 64) red[PCG_UPD_TPB + threadIdx.x] = 0.0;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
-    const double pap = red[0];
-    const double rz_old = sc[0];
-    const double alpha = pap > 0.0 ? rz_old / pap : 0.0;
     const long long n = 6LL * nfree;
     const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
+    // everything this thread needs is requested before the reduction, so that all global loads overlap
+    double r_old[6], ap[6], mi[6], x_old = 0, p_old = 0;
+    const long long f = o < n ? o / 6 : 0; const int i = (int)(o < n ? o - 6 * f : 0);
+#pragma unroll
+    for (int j = 0; j < 6; j++) { r_old[j] = w[n + 6 * f + j]; ap[j] = w[4 * n + 6 * f + j]; mi[j] = Minv[36 * f + i * 6 + j]; }
+    if (o < n) { x_old = w[o]; p_old = w[3 * n + o]; }
+    const double rz_old = sc[8 + parity];
+    double s = 0;
+#pragma unroll 4
+    for (int k = threadIdx.x; k < nfree; k += PCG_UPD_TPB) s += pap_part[k];
+    for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double pap = (red[0] + red[1]) + red[2];
+    const double alpha = pap > 0.0 ? rz_old / pap : 0.0;
     double rz = 0, rr = 0, xi = 0, ri = 0, z = 0;
     if (o < n) {
-        const long long f = o / 6; const int i = (int)(o - 6 * f);
         double rn[6];
-        for (int j = 0; j < 6; j++) rn[j] = w[n + 6 * f + j] - alpha * w[4 * n + 6 * f + j];
-        for (int j = 0; j < 6; j++) z += Minv[36 * f + i * 6 + j] * rn[j];
-        xi = w[o] + alpha * w[3 * n + o];
+#pragma unroll
+        for (int j = 0; j < 6; j++) rn[j] = r_old[j] - alpha * ap[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) z += mi[j] * rn[j];
+        xi = x_old + alpha * p_old;
         ri = rn[i];
         rz = ri * z; rr = ri * ri;
     }
@@ -397,16 +405,25 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
 }
 
 // beta = rz_new / rz_old; p = z + beta p; publish the scalars (block 0)
-__global__ __launch_bounds__(256) void k_pcg_dir(int nfree, int nblk, double* __restrict__ w, const double* __restrict__ part, double* __restrict__ sc)
+// r.z lives in two alternating slots sc[8], sc[9]: iteration `parity` reads its slot and block 0 writes the other,
+// so no block can see the new value while another still needs the old one.
+__global__ __launch_bounds__(256) void k_pcg_dir(int nfree, int nblk, double* __restrict__ w, const double* __restrict__ part, double* __restrict__ sc, int parity)
 {
-    double rz = 0, rr = 0;
-    for (int i = 0; i < nblk; i++) { rz += part[3 * i]; rr += part[3 * i + 1]; }
-    const double rz_old = sc[0];
-    const double beta = rz_old > 0.0 ? rz / rz_old : 0.0;
+    __shared__ double red[4];
     const long long n = 6LL * nfree;
     const long long i = blockIdx.x * 256LL + threadIdx.x;
-    if (i < n) w[3 * n + i] = w[2 * n + i] + beta * w[3 * n + i];
+    double zi = 0, pi = 0;
+    if (i < n) { zi = w[2 * n + i]; pi = w[3 * n + i]; }
+    const double rz_old = sc[8 + parity];
+    double rz = 0;
+    for (int k = threadIdx.x; k < nblk; k += 256) rz += part[3 * k];     // fixed assignment + fixed tree: reproducible
+    for (int st = 32; st >= 1; st >>= 1) rz += __shfl_xor(rz, st, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = rz;
     __syncthreads();
+    rz = (red[0] + red[1]) + (red[2] + red[3]);
+    const double beta = rz_old > 0.0 ? rz / rz_old : 0.0;
+    if (i < n) w[3 * n + i] = zi + beta * pi;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[8 + (parity ^ 1)] = rz;
 }
 __global__ __launch_bounds__(64) void k_pcg_scalars(int nblk, const double* __restrict__ part, double* __restrict__ sc)
 {
@@ -491,12 +508,12 @@ void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfr
 }
 // `first` = this is the first iteration since pcg_launch_init or pcg_launch_publish (nothing pending to publish)
 void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc, int first)
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int first, int parity)
 {
     const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
     hipLaunchKernelGGL(k_pcg_spmv, dim3(nfree), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, first ? 0 : 1, nb, part, sc);
-    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part);
-    hipLaunchKernelGGL(k_pcg_dir, dim3(nblk(6LL * nfree, 256)), dim3(256), 0, s, nfree, nb, w, part, sc);
+    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity);
+    hipLaunchKernelGGL(k_pcg_dir, dim3(nblk(6LL * nfree, 256)), dim3(256), 0, s, nfree, nb, w, part, sc, parity);
 }
 // publish the scalars of the last iteration (before the host reads them)
 void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc)

@@ -285,6 +285,8 @@ int ccm_pose_optimize(ccm_ctx*, ccm_pose_problem*);
  * camera system is summed with one RCCL all-reduce per LM trial.  One rank
  * makes an id, the host program distributes it (e.g. torch.distributed
  * broadcast), every rank calls ccm_comm_init.  */
+/* The landmark ranges ccm_ba_solve gives to the ranks (host only, no GPU): cuts[r] .. cuts[r+1]-1 -> rank r. */
+int ccm_ba_landmark_cuts(const int32_t* edge_point, int n_edges, int n_points, int n_ranks, int32_t* cuts);
 #define CCM_COMM_ID_BYTES 128
 int ccm_comm_unique_id(uint8_t id[CCM_COMM_ID_BYTES]);
 int ccm_comm_init(ccm_ctx*, const uint8_t id[CCM_COMM_ID_BYTES], int n_ranks, int rank);

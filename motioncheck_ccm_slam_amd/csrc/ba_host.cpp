@@ -125,6 +125,29 @@ int ccm_pose_to_mat4f(const double* pose, float* T)
     return CCM_OK;
 }
 
+// Landmark ranges of the ranks of a sharded global BA: contiguous, balanced by the Schur cost
+// k(k+1)/2 + k + 1 of a k-observation landmark.  cuts[r] .. cuts[r+1]-1 belong to rank r.  Host only.
+int ccm_ba_landmark_cuts(const int32_t* edge_point, int n_edges, int n_points, int n_ranks, int32_t* cuts)
+{
+    if (!cuts || n_ranks < 1 || n_points < 0 || n_edges < 0 || (n_edges > 0 && !edge_point)) return CCM_E_ARG;
+    std::vector<int> deg(n_points, 0);
+    for (int e = 0; e < n_edges; e++) {
+        if (edge_point[e] < 0 || edge_point[e] >= n_points) return CCM_E_ARG;
+        deg[edge_point[e]]++;
+    }
+    double total = 0;
+    for (int l = 0; l < n_points; l++) total += 0.5 * deg[l] * (deg[l] + 1) + deg[l] + 1;
+    for (int r = 0; r <= n_ranks; r++) cuts[r] = n_points;
+    cuts[0] = 0;
+    double acc = 0;
+    int r = 0;
+    for (int l = 0; l < n_points; l++) {
+        acc += 0.5 * deg[l] * (deg[l] + 1) + deg[l] + 1;
+        while (r + 1 < n_ranks && acc >= total * (r + 1) / n_ranks) cuts[++r] = l + 1;
+    }
+    return CCM_OK;
+}
+
 int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_ba_result* res)
 {
     if (!c || !pb || !opt) return CCM_E_ARG;
@@ -165,18 +188,10 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     const long long n = 6LL * nfree;
 
     // ---- landmark shard of this rank: contiguous range balanced by Schur cost k(k+1)/2 + k
-    std::vector<int> deg(Lall, 0);
-    for (int e = 0; e < Eall; e++) deg[pb->edge_point[e]]++;
     int l0 = 0, l1 = Lall;
     if (ranks > 1) {
-        double total = 0;
-        for (int l = 0; l < Lall; l++) total += 0.5 * deg[l] * (deg[l] + 1) + deg[l] + 1;
-        double acc = 0; int r = 0; l0 = 0; l1 = Lall;
-        std::vector<int> cut(ranks + 1, Lall); cut[0] = 0;
-        for (int l = 0; l < Lall; l++) {
-            acc += 0.5 * deg[l] * (deg[l] + 1) + deg[l] + 1;
-            while (r + 1 < ranks && acc >= total * (r + 1) / ranks) { cut[++r] = l + 1; }
-        }
+        std::vector<int32_t> cut(ranks + 1);
+        ccm_ba_landmark_cuts(pb->edge_point, Eall, Lall, ranks, cut.data());
         l0 = cut[rank]; l1 = cut[rank + 1];
     }
     const int L = l1 - l0;

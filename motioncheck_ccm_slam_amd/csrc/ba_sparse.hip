@@ -145,46 +145,52 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double*
     }
 }
 
-// one wave per block: lane (i,j) < 36 sums its element over the block's pairs in sorted order
+// One wave per block.  Per step the wave fetches the operands of four pairs with ONE load per lane each (lanes
+// 0..17: Y_a = Hpl_a Dinv, lanes 18..35: Hpl_b; 288 bytes per pair), parks them in its LDS slice and every lane
+// (i,j) < 36 then reads the six values it needs from LDS.  Four fixed accumulation chains, combined as
+// (s0+s1)+(s2+s3): the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                                                          const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb,
                                                          double* __restrict__ Hb)
 {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (b >= nb || lane >= 36) return;
-    const int i = lane / 6, j = lane - 6 * i;
+    __shared__ double stage[4][4][36];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= nb) return;
+    const int i = lane / 6, j = lane - 6 * i;              // meaningful for lane < 36
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     const int p0 = seg_start[b], p1 = seg_end[b];
-    int p = p0;
-    // four independent chains keep four pairs' loads in flight; the grouping is fixed, so the sum is reproducible
-    for (; p + 3 < p1; p += 4) {
-        unsigned long long v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = pairs[p + q];
-        double ya[4][3], hb[4][3];
+    double (*st)[36] = stage[wv];
+    for (int p = p0; p < p1; p += 4) {
+        double v[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const double* y = Y + 18 * (long long)(unsigned)(v[q] >> 32) + 3 * i;
-            const double* h = D.Hpl + 18 * (long long)(unsigned)(v[q] & 0xFFFFFFFFu) + 3 * j;
-            ya[q][0] = y[0]; ya[q][1] = y[1]; ya[q][2] = y[2];
-            hb[q][0] = h[0]; hb[q][1] = h[1]; hb[q][2] = h[2];
+            v[q] = 0.0;
+            if (lane < 36 && p + q < p1) {
+                const unsigned long long pr = pairs[p + q];
+                v[q] = lane < 18 ? Y[18 * (long long)(unsigned)(pr >> 32) + lane]
+                                 : D.Hpl[18 * (long long)(unsigned)(pr & 0xFFFFFFFFu) + (lane - 18)];
+            }
         }
-        s0 += ya[0][0] * hb[0][0] + ya[0][1] * hb[0][1] + ya[0][2] * hb[0][2];
-        s1 += ya[1][0] * hb[1][0] + ya[1][1] * hb[1][1] + ya[1][2] * hb[1][2];
-        s2 += ya[2][0] * hb[2][0] + ya[2][1] * hb[2][1] + ya[2][2] * hb[2][2];
-        s3 += ya[3][0] * hb[3][0] + ya[3][1] * hb[3][1] + ya[3][2] * hb[3][2];
+        if (lane < 36) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) st[q][lane] = v[q];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // this wave's LDS stores have landed
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 36) {
+            s0 += st[0][3 * i] * st[0][18 + 3 * j] + st[0][3 * i + 1] * st[0][19 + 3 * j] + st[0][3 * i + 2] * st[0][20 + 3 * j];
+            s1 += st[1][3 * i] * st[1][18 + 3 * j] + st[1][3 * i + 1] * st[1][19 + 3 * j] + st[1][3 * i + 2] * st[1][20 + 3 * j];
+            s2 += st[2][3 * i] * st[2][18 + 3 * j] + st[2][3 * i + 1] * st[2][19 + 3 * j] + st[2][3 * i + 2] * st[2][20 + 3 * j];
+            s3 += st[3][3 * i] * st[3][18 + 3 * j] + st[3][3 * i + 1] * st[3][19 + 3 * j] + st[3][3 * i + 2] * st[3][20 + 3 * j];
+        }
+        __builtin_amdgcn_wave_barrier();                   // reads done before the next step overwrites the slice
     }
-    for (; p < p1; p++) {
-        const unsigned long long v0 = pairs[p];
-        const double* ya = Y + 18 * (long long)(unsigned)(v0 >> 32) + 3 * i;
-        const double* hb = D.Hpl + 18 * (long long)(unsigned)(v0 & 0xFFFFFFFFu) + 3 * j;
-        s0 += ya[0] * hb[0] + ya[1] * hb[1] + ya[2] * hb[2];
-    }
-    s0 = (s0 + s1) + (s2 + s3); s1 = 0;
+    if (lane >= 36) return;
     const int r = blk_row[b], c = blk_col[b];
     const double base = r == c ? D.Hpp[36 * (long long)r + lane] : 0.0;
-    Hb[36 * (long long)b + lane] = base - (s0 + s1);
+    Hb[36 * (long long)b + lane] = base - ((s0 + s1) + (s2 + s3));
 }
 
 // one wave per free pose: bs = bp - sum over its edges of Hpl_e db(l_e), fixed order

@@ -74,3 +74,18 @@ def test_landmark_cuts_balance():
         cost = 0.5 * deg * (deg + 1) + deg + 1
         per = [cost[cuts[r]:cuts[r + 1]].sum() for r in range(ranks)]
         assert max(per) < 1.1 * cost.sum() / ranks + cost.max()
+
+
+def test_cxx_landmark_cuts_equal_python_rule():
+    """The C++ partition used inside ccm_ba_solve (host-only entry point) is the rule the gloo test sums over."""
+    import ctypes as C
+    from motioncheck_ccm_slam_amd import _lib, synth, dist as D
+    lib = _lib.load()
+    g = synth.gba_graph(n_kf=90, n_points=7000, n_agents=3, seed=9)
+    ep = np.ascontiguousarray(g["edge_point"], "i4")
+    for ranks in (1, 2, 3, 4, 8):
+        cuts = np.zeros(ranks + 1, "i4")
+        assert lib.ccm_ba_landmark_cuts(_lib.ptr(ep), len(ep), len(g["points"]), ranks, _lib.ptr(cuts)) == 0
+        assert (cuts == D.landmark_cuts(ep, len(g["points"]), ranks)).all()
+    bad = ep.copy(); bad[0] = 10 ** 6
+    assert lib.ccm_ba_landmark_cuts(_lib.ptr(bad), len(bad), len(g["points"]), 2, _lib.ptr(np.zeros(3, "i4"))) == -1

@@ -31,6 +31,7 @@ W, H = 752, 480
 ALG_BYTES = {
     "k_pyr_resize": 360960 + 756407,                 # read level 0, write levels 1..7
     "k_fast_score": 1117367,                         # FAST reads every pyramid pixel once
+    "k_fast_cells": 1117367,                         # fused score + per-cell NMS (the default path): same algorithmic read
     "k_cell_nms": 0, "k_octree": 0,                  # candidate lists: not in the survey's figure
     "k_orient_desc": 2234734 + 1982000,              # blur read+write (fused here) + 1000 kp patches/desc/kp
 }
@@ -125,6 +126,8 @@ def main():
         if n:
             per_step = ms / args.steps
             kern[k] = {"ms_per_step": round(per_step, 4), "launches_per_step": n // args.steps}
+    if "k_cell_nms" not in kern and "k_fast_score" in kern:      # the fused kernel is timed under the score label
+        kern["k_fast_cells"] = kern.pop("k_fast_score")
     dom = max((k for k in kern if k in ALG_BYTES), key=lambda k: kern[k]["ms_per_step"])
     dom_bytes = ALG_BYTES[dom] * FRAMES
     dom_s = kern[dom]["ms_per_step"] * 1e-3

@@ -12,6 +12,9 @@ size_t orb_octree_lds_bytes(int list_cap);
 void orb_launch_resize(hipStream_t, const OrbGeom&, int level, int dw, int dh, int nframes);
 void orb_launch_score(hipStream_t, const OrbGeom&, int ntiles, int nframes);
 void orb_launch_nms(hipStream_t, const OrbGeom&, const OrbCell*, int ncells, int nframes, unsigned* slots, int* cell_count);
+void orb_launch_fast_cells(hipStream_t, const OrbGeom&, const OrbCell*, const OrbBand*, int nbands, int nframes, size_t lds_bytes,
+                           int surv_cap, unsigned* slots, int* cell_count);
+size_t orb_fast_cells_lds(int pitch, int bh, int surv_cap);
 void orb_launch_octree(hipStream_t, const OrbGeom&, const OrbCell*, int nlevels, int nframes, int list_cap,
                        const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
                        unsigned* out, int* out_count, int* status);
@@ -94,7 +97,8 @@ struct OrbState {
     OrbTables tab{};
     OrbGeom geom{};
     std::vector<OrbCell> cells;
-    DevBuf geom_dev, cells_dev, tables_dev;
+    std::vector<OrbBand> bands; size_t band_lds = 0; bool fused = true; int surv_cap = 1024;
+    DevBuf geom_dev, cells_dev, tables_dev, bands_dev;
     DevBuf pyr, smap, slots, cell_count, keysA, keysB, sel, sel_count, status;
     DevBuf img0;                   // staging for the host-pointer entry point
     DevBuf kps, desc, counts;      // results
@@ -106,7 +110,7 @@ struct OrbState {
 void orb_state_free(OrbState* s)
 {
     if (!s) return;
-    DevBuf* all[] = { &s->geom_dev, &s->cells_dev, &s->tables_dev, &s->pyr, &s->smap, &s->slots, &s->cell_count,
+    DevBuf* all[] = { &s->geom_dev, &s->cells_dev, &s->tables_dev, &s->bands_dev, &s->pyr, &s->smap, &s->slots, &s->cell_count,
                       &s->keysA, &s->keysB, &s->sel, &s->sel_count, &s->status, &s->img0, &s->kps, &s->desc, &s->counts };
     for (DevBuf* b : all) b->release();
     delete s;
@@ -206,6 +210,34 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
         L.tiles_x = (L.w + 63) / 64; L.tiles_y = (L.h + 63) / 64;      // ST_W x ST_H of k_fast_score
         L.tile_first = tile_acc; tile_acc += L.tiles_x * L.tiles_y;
     }
+    // bands of the fused FAST kernel: runs of consecutive cells of one cell row whose LDS tile stays small
+    S.bands.clear(); S.band_lds = 0;
+    static const bool want_fused = !(getenv("CCM_ORB_FUSED") && atoi(getenv("CCM_ORB_FUSED")) == 0);
+    S.fused = want_fused;
+    static const int pcap = getenv("CCM_FC_PCAP") ? std::min(atoi(getenv("CCM_FC_PCAP")), 256) : 160;      // pitch <= 256: one dword per lane
+    static const int scap = getenv("CCM_FC_SURV") ? atoi(getenv("CCM_FC_SURV")) : 2048;
+    S.surv_cap = scap;
+    for (size_t a = 0; a < S.cells.size();) {
+        size_t b = a;
+        const OrbCell& c0 = S.cells[a];
+        const int xa = (c0.x0 - 4) & ~3;
+        int pitch = 0;
+        while (b < S.cells.size() && S.cells[b].level == c0.level && S.cells[b].y0 == c0.y0) {
+            const int p2 = (int)align_up((size_t)(S.cells[b].x0 + S.cells[b].cw + 4 - xa), 4);
+            if (b > a && p2 > pcap) break;
+            pitch = p2; b++;
+        }
+        OrbBand band{};
+        band.cell_first = (int)a; band.ncells = (int)(b - a); band.level = c0.level; band.xa = (short)xa; band.y0 = c0.y0;
+        band.pitch = (short)pitch; band.bh = c0.ch;
+        for (size_t k = a; k < b; k++) if (S.cells[k].ch != c0.ch) S.fused = false;      // cannot happen: one row, one height
+        S.surv_cap = std::max(S.surv_cap, pitch);                 // at least one row per block
+        S.band_lds = std::max(S.band_lds, orb_fast_cells_lds(pitch, c0.ch, std::max(scap, pitch)));
+        S.bands.push_back(band);
+        a = b;
+    }
+    for (const OrbBand& b : S.bands) if (b.pitch > 256) S.fused = false;    // a single cell wider than the tile: two-kernel path
+    if (S.band_lds > 60 * 1024) S.fused = false;                 // very large cells: keep the two-kernel path
     G.ncells = (int)S.cells.size(); G.ntiles = tile_acc;
     G.slots_per_frame = std::max(slot_acc, 1); G.keys_per_frame = key_acc; G.out_per_frame = out_acc;
     int list_cap = 0;
@@ -231,6 +263,7 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
     const size_t tab_bytes = align_up(tab_i.size() * 4, 16) + tab_s.size() * 2;
     CCM_RESERVE(c, S.tables_dev, std::max<size_t>(tab_bytes, 16));
     CCM_RESERVE(c, S.cells_dev, std::max<size_t>(S.cells.size(), 1) * sizeof(OrbCell));
+    CCM_RESERVE(c, S.bands_dev, std::max<size_t>(S.bands.size(), 1) * sizeof(OrbBand));
     CCM_RESERVE(c, S.geom_dev, sizeof(OrbGeom));
     char* tb = S.tables_dev.as<char>();
     const size_t s_base = align_up(tab_i.size() * 4, 16);
@@ -249,6 +282,8 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
     if (!tab_s.empty()) CCM_HIP(c, hipMemcpyAsync(tb + s_base, tab_s.data(), tab_s.size() * 2, hipMemcpyHostToDevice, c->stream));
     if (!S.cells.empty())
         CCM_HIP(c, hipMemcpyAsync(S.cells_dev.p, S.cells.data(), S.cells.size() * sizeof(OrbCell), hipMemcpyHostToDevice, c->stream));
+    if (!S.bands.empty())
+        CCM_HIP(c, hipMemcpyAsync(S.bands_dev.p, S.bands.data(), S.bands.size() * sizeof(OrbBand), hipMemcpyHostToDevice, c->stream));
     CCM_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors above go out of scope
     if (!S.pattern_up) { CCM_HIP(c, orb_upload_pattern()); S.pattern_up = true; }
     S.par = *p; S.w = w; S.h = h; S.nframes = nframes; S.max_per_image = max_per_image;
@@ -268,8 +303,13 @@ static int orb_run(ccm_ctx* c, const uint8_t* img_dev, int stride, size_t image_
     hipStream_t st = c->stream;
     CCM_HIP(c, hipMemsetAsync(S.status.p, 0, 4, st));
     for (int l = 1; l < G.nlevels; l++) { ProfScope ps(c, CCM_PROF_RESIZE); orb_launch_resize(st, gd, l, G.lv[l].w, G.lv[l].h, S.nframes); }
-    { ProfScope ps(c, CCM_PROF_FAST_SCORE); orb_launch_score(st, gd, G.ntiles, S.nframes); }
-    if (G.ncells > 0) { ProfScope ps(c, CCM_PROF_CELL_NMS); orb_launch_nms(st, gd, cd, G.ncells, S.nframes, S.slots.as<unsigned>(), S.cell_count.as<int>()); }
+    if (S.fused && !S.bands.empty()) {
+        ProfScope ps(c, CCM_PROF_FAST_SCORE);
+        orb_launch_fast_cells(st, gd, cd, S.bands_dev.as<OrbBand>(), (int)S.bands.size(), S.nframes, S.band_lds, S.surv_cap, S.slots.as<unsigned>(), S.cell_count.as<int>());
+    } else {
+        { ProfScope ps(c, CCM_PROF_FAST_SCORE); orb_launch_score(st, gd, G.ntiles, S.nframes); }
+        if (G.ncells > 0) { ProfScope ps(c, CCM_PROF_CELL_NMS); orb_launch_nms(st, gd, cd, G.ncells, S.nframes, S.slots.as<unsigned>(), S.cell_count.as<int>()); }
+    }
     { ProfScope ps(c, CCM_PROF_OCTREE);
     orb_launch_octree(st, gd, cd, G.nlevels, S.nframes, G.list_cap, S.slots.as<unsigned>(), S.cell_count.as<int>(),
                       S.keysA.as<unsigned>(), S.keysB.as<unsigned>(), S.sel.as<unsigned>(), S.sel_count.as<int>(),

@@ -338,6 +338,156 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_fast_cells: k_fast_score + k_cell_nms fused on a band = a run of cells of one cell row.  The band's pixels
+// are staged once in LDS, scored in LDS (rejection test -> survivor list -> dense scoring, in row blocks), and
+// each cell's threshold choice / 3x3 NMS / ordered compaction runs straight from the LDS score tile: the score
+// map never goes to HBM.  Bands of adjacent cell rows overlap by 6 rows, which are scored twice.
+// the survivor list holds `surv_cap` pixels; the detection rows are processed in blocks of surv_cap / pitch rows
+__host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap) { return 2 * (size_t)pitch * bh + (size_t)surv_cap * 2 + 32; }
+
+__global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
+                                                    unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
+    const OrbBand B = bands[blockIdx.x];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const OrbLevel& L = g.lv[B.level];
+    const int P = B.pitch, bh = B.bh, PW = P >> 2;
+    uint8_t* T = fc_smem;                                   // pixels  [bh][P]
+    uint8_t* S = fc_smem + (size_t)P * bh;                  // scores  [bh][P]
+    unsigned short* surv = reinterpret_cast<unsigned short*>(S + (size_t)P * bh);
+    int* nsurv = reinterpret_cast<int*>(surv + FC_SURV);
+    const uint8_t* img = L.img + (long long)f * L.plane;
+    // ---- stage pixels (clamped: duplicates are only read for pixels whose score is not needed), zero the scores
+    const bool dword_ok = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)L.pitch) & 3) == 0 && L.pitch >= ((L.w + 3) & ~3);
+    // i / PW by multiply-shift: exact for i < 2^20 / PW (i <= 65 * 64 here)
+    const unsigned pw_inv = (1u << 20) / (unsigned)PW + 1u;
+    if (dword_ok) {
+        const int wmax = ((L.w - 1) & ~3);
+        for (int i = tid; i < bh * PW; i += 256) {
+            const int ly = (int)(((unsigned)i * pw_inv) >> 20), lx = i - ly * PW;
+            const int gy = min(B.y0 + ly, L.h - 1), gx = min(B.xa + 4 * lx, wmax);
+            reinterpret_cast<unsigned*>(T)[i] = *reinterpret_cast<const unsigned*>(img + (long long)gy * L.pitch + gx);
+            reinterpret_cast<unsigned*>(S)[i] = 0u;
+        }
+    } else {
+        for (int i = tid; i < bh * P; i += 256) {
+            const int ly = i / P, lx = i - ly * P;
+            const int gy = min(B.y0 + ly, L.h - 1), gx = min(B.xa + lx, L.w - 1);
+            T[i] = img[(long long)gy * L.pitch + gx];
+            S[i] = 0;
+        }
+    }
+    // columns of the tile that belong to some cell's detection area: [c_lo, c_hi)
+    const OrbCell cfirst = cells[B.cell_first], clast = cells[B.cell_first + B.ncells - 1];
+    const int c_lo = cfirst.x0 + 3 - B.xa, c_hi = clast.x0 + clast.cw - 3 - B.xa;
+    const int t_lo = min(g.ini_th, g.min_th);
+    const int RB = max(1, FC_SURV / P);                      // rows per block: at most FC_SURV pixels
+    __syncthreads();
+    for (int r0 = 3; r0 < bh - 3; r0 += RB) {
+        if (tid == 0) *nsurv = 0;
+        __syncthreads();
+        const int r1 = min(r0 + RB, bh - 3);
+        const int items = (r1 - r0) * PW;
+        for (int it0 = 0; it0 < items; it0 += 256) {           // uniform trip count: the ballots below need whole waves
+            const int it = it0 + tid;
+            const int rr = (int)(((unsigned)it * pw_inv) >> 20);
+            const int row = r0 + rr, dw = it - rr * PW;
+            const int px = 4 * dw;
+            unsigned keep4 = 0;
+            if (it < items && px + 3 >= c_lo && px < c_hi && dw >= 1 && dw + 1 < PW) {
+                const unsigned* crow = reinterpret_cast<const unsigned*>(T + row * P) + dw;
+                const unsigned c0 = crow[-1], c1 = crow[0], c2 = crow[1];
+                const unsigned nn = reinterpret_cast<const unsigned*>(T + (row + 3) * P)[dw];
+                const unsigned ss = reinterpret_cast<const unsigned*>(T + (row - 3) * P)[dw];
+                const unsigned long long lo = ((unsigned long long)c1 << 32) | c0, hi = ((unsigned long long)c2 << 32) | c1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int col = px + i;
+                    if (col < c_lo || col >= c_hi) continue;
+                    const int v = (int)((c1 >> (8 * i)) & 0xFF);
+                    const int n = (int)((nn >> (8 * i)) & 0xFF), s2 = (int)((ss >> (8 * i)) & 0xFF);
+                    const int w = (int)((lo >> (8 * (i + 1))) & 0xFF);         // column col-3 = byte 4+i-3 of c0|c1|c2
+                    const int e = (int)((hi >> (8 * (i + 3))) & 0xFF);         // column col+3 = byte 4+i+3
+                    const bool keep = !((abs(v - n) <= t_lo && abs(v - s2) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo));
+                    keep4 |= keep ? (1u << i) : 0u;
+                }
+            }
+            if (__ballot(keep4 != 0u) != 0ull) {               // survivors are rare: one ballot decides for the wave
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool keep = (keep4 >> i) & 1u;
+                    const unsigned long long m = __ballot(keep);
+                    if (m != 0ull) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(nsurv, __popcll(m));
+                        base = __shfl(base, 0, 64);
+                        const int pos = base + __popcll(m & lanemask_lt());
+                        if (keep && pos < FC_SURV) surv[pos] = (unsigned short)(row * P + px + i);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int ns = min(*nsurv, FC_SURV);
+        for (int si = tid; si < ns; si += 256) {
+            const int pos = surv[si];
+            const uint8_t* c = T + pos;
+            const int v = c[0];
+            int r[16];
+            r[0] = c[3 * P];      r[1] = c[3 * P + 1];  r[2] = c[2 * P + 2];  r[3] = c[P + 3];
+            r[4] = c[3];          r[5] = c[-P + 3];     r[6] = c[-2 * P + 2]; r[7] = c[-3 * P + 1];
+            r[8] = c[-3 * P];     r[9] = c[-3 * P - 1]; r[10] = c[-2 * P - 2]; r[11] = c[-P - 3];
+            r[12] = c[-3];        r[13] = c[P - 3];     r[14] = c[2 * P - 2]; r[15] = c[3 * P - 1];
+            const int sc = fast_score16(v, r);
+            if (sc >= t_lo && sc > 0) S[pos] = (uint8_t)sc;
+        }
+        __syncthreads();
+    }
+    // ---- per cell: threshold choice, strict 3x3 NMS inside the cell's detection rectangle, ordered compaction
+    for (int ci = wv; ci < B.ncells; ci += 4) {
+        const OrbCell c = cells[B.cell_first + ci];
+        const int rw = c.cw - 6, rh = c.ch - 6;
+        int* count_out = cell_count + (long long)f * g.ncells + B.cell_first + ci;
+        if (rw <= 0 || rh <= 0) { if (lane == 0) *count_out = 0; continue; }
+        const uint8_t* S0 = S + 3 * P + (c.x0 + 3 - B.xa);                    // score of the rectangle's first pixel
+        unsigned* out = slots + (long long)f * g.slots_per_frame + c.slot_first;
+        const int relx = c.x0 + 3 - ORB_BORDER, rely = c.y0 + 3 - ORB_BORDER;
+        const int rpi = rw <= 32 ? 2 : 1;
+        const int xx = rpi == 2 ? (lane & 31) : lane, yoff = rpi == 2 ? (lane >> 5) : 0;
+        int n = 0;
+        for (int attempt = 0; attempt < 2 && n == 0; attempt++) {
+            const int th = attempt == 0 ? g.ini_th : g.min_th;
+            for (int y0 = 0; y0 < rh; y0 += rpi) {
+                const int yy = y0 + yoff;
+                const bool in = yy < rh && xx < rw;
+                const uint8_t* p = S0 + min(yy, rh - 1) * P + min(xx, rw - 1);
+                const int s = in ? p[0] : 0;
+                if (__ballot(s >= th && s > 0) == 0ull) continue;              // most rows hold no corner
+                bool keep = false;
+                if (s >= th && s > 0) {
+                    // neighbours outside the cell's rectangle, and scores below the threshold, count as 0
+                    const bool l = xx > 0, r = xx + 1 < rw, u = yy > 0, d = yy + 1 < rh;
+#define NB(c, o) ((c) && (int)p[o] >= th ? (int)p[o] : 0)
+                    keep = s > NB(l, -1) && s > NB(r, 1) &&
+                           s > NB(u && l, -P - 1) && s > NB(u, -P) && s > NB(u && r, -P + 1) &&
+                           s > NB(d && l, P - 1) && s > NB(d, P) && s > NB(d && r, P + 1);
+#undef NB
+                }
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int pos = n + __popcll(m & lanemask_lt());
+                    if (pos < c.slot_cap)
+                        out[pos] = ((unsigned)s << 24) | ((unsigned)(rely + yy) << 12) | (unsigned)(relx + xx);
+                }
+                n += __popcll(m);
+            }
+        }
+        if (lane == 0) *count_out = n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_octree: DistributeOctTree (ORBextractor.cpp:707-931), one wave per (frame, level).
 //
 // The reference keeps nodes in a std::list, inserting children with push_front and erasing the
@@ -884,6 +1034,12 @@ void orb_launch_nms(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, i
 {
     hipLaunchKernelGGL(k_cell_nms, dim3((ncells + 3) / 4, nframes), dim3(256), 0, s, g_dev, cells, slots, cell_count);
 }
+void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, const OrbBand* bands, int nbands, int nframes,
+                           size_t lds_bytes, int surv_cap, unsigned* slots, int* cell_count)
+{
+    hipLaunchKernelGGL(k_fast_cells, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap);
+}
+size_t orb_fast_cells_lds(int pitch, int bh, int surv_cap) { return fc_lds_bytes(pitch, bh, surv_cap); }
 void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,
                        const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
                        unsigned* out, int* out_count, int* status)

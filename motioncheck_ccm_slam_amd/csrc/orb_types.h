@@ -38,6 +38,12 @@ struct OrbCell {
     int slot_first, slot_cap;           // per-frame candidate slots of this cell
 };
 
+// One workgroup of the fused FAST kernel: a run of cells of one cell row (k_fast_cells)
+struct OrbBand {
+    int cell_first, ncells;            // consecutive cells of one row of one level
+    short level, xa, y0, pitch, bh, pad; // tile origin (xa multiple of 4, one spare dword left of the first cell), LDS pitch, rows
+};
+
 struct OrbGeom {
     int nlevels, ncells, ntiles;
     int ini_th, min_th;

@@ -164,10 +164,14 @@ def main():
                "sample": "the same %d frames + %d consecutive-pair matches, scalar C oracle on 1 core "
                          "(extract %.2f s, match %.2f s); host has %d cores" % (FRAMES, FRAMES - 1, t2 - t1, t3 - t2, os.cpu_count())}
 
-    # ---- global BA (config 5): LM iterations per second
-    gba = None
-    if not args.no_gba:
+    # ---- global BA (config 5): LM iterations per second.  Runs in a worker thread with a deadline: with N > 1 it
+    # is the only part that talks over RCCL, and a communicator that never completes must not cost the
+    # extract+match result (the thread cannot be cancelled, so on a timeout the process reports and hard-exits).
+    gba_box = {}
+
+    def run_gba():
         try:
+            torch.cuda.set_device(local)                                # the current device is per thread
             from motioncheck_ccm_slam_amd.optimizer import Optimizer
             if world > 1:
                 D.init_comm(ctx, rank, world)
@@ -187,6 +191,7 @@ def main():
                    "lm_seconds": round(lm_s, 4), "call_seconds_incl_graph_upload": round(call_s, 4),
                    "t_linearize": round(r["t_linearize"], 4), "t_schur": round(r["t_schur"], 4),
                    "t_solve": round(r["t_solve"], 4), "t_update": round(r["t_update"], 4),
+                   "schur_blocks": r["schur_blocks"], "schur_pairs_this_rank": r["schur_pairs"], "pcg_iterations": r["pcg_iterations"],
                    "chi2_initial": r["chi2_initial"], "chi2_final": r["chi2_final"], "n_gpus": world, "scaling": "strong",
                    "dtype": "f64"}
             if rank == 0 and world == 1 and not args.no_cpu:
@@ -197,8 +202,19 @@ def main():
                 tc = time.perf_counter() - tc
                 gba["cpu_baseline"] = {"value": round(rc["iterations_done"] / tc, 4), "unit": "LM iterations/s", "cores": 1, "kind": "port",
                                        "sample": "300 KF / 30k points / %d edges (the oracle's dense solve does not scale to 2000 KF)" % len(gs["edge_pose"])}
+            gba_box["gba"] = gba
         except Exception as e:  # the headline number must survive a communicator problem
-            gba = {"error": "%s: %s" % (type(e).__name__, e)}
+            gba_box["gba"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    gba = None
+    timed_out = False
+    if not args.no_gba:
+        import threading
+        th = threading.Thread(target=run_gba, daemon=True)
+        th.start()
+        th.join(timeout=300.0)
+        timed_out = th.is_alive()
+        gba = {"error": "timeout: global BA did not finish within 300 s"} if timed_out else gba_box.get("gba")
 
     if rank == 0:
         out = {
@@ -212,7 +228,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "gba": gba,
             "frames_per_s": round(FRAMES * world * args.steps / dt, 1),
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if timed_out:
+        os._exit(0)                 # a stuck collective cannot be cancelled; the result line is already out
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -210,6 +210,13 @@ int ccm_search_by_projection_frame(ccm_ctx*, const ccm_frame_grid* current, cons
                                    const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied,
                                    float th, int check_ori, int32_t* match);
 
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cpp:448-563).
+ * prev_matched_xy [n1][2] is vbPrevMatched (updated for matched features as :556-558); matches12[i1] = index into
+ * F2 or -1.  Returns nmatches. */
+int ccm_search_for_initialization(ccm_ctx*, int n1, const int32_t* oct1, const uint8_t* desc1, const float* angle1,
+                                  const ccm_frame_grid* f2, const float* angle2, float* prev_matched_xy, int window,
+                                  float nnratio, int check_ori, int32_t* matches12);
+
 /* ---------------------------------------------------------------- optimizer
  * The 6-DoF pose / 3-DoF point reprojection BA that Optimizer::BundleAdjustmentClient
  * (src/Optimizer.cpp:32-212), LocalBundleAdjustmentClient (:349-644) and

@@ -2,6 +2,7 @@
 // ORBmatcher::SearchByBoW (cslam/src/ORBmatcher.cpp:178-306, 565-698).
 #include "ccm_internal.h"
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <numeric>
 
@@ -423,6 +424,76 @@ int ccm_search_by_projection_frame(ccm_ctx* c, const ccm_frame_grid* f, const fl
             for (int idx : rot[b]) { match[idx] = -1; nmatches--; }
         }
     }
+    return nmatches;
+}
+
+// ORBmatcher::SearchForInitialization, ORBmatcher.cpp:448-563
+int ccm_search_for_initialization(ccm_ctx* c, int n1, const int32_t* oct1, const uint8_t* desc1, const float* angle1,
+                                  const ccm_frame_grid* f2, const float* angle2, float* prev_matched_xy, int window, float nnratio,
+                                  int check_ori, int32_t* matches12)
+{
+    if (!c || !f2) return CCM_E_ARG;
+    if (n1 < 0 || f2->n < 0 || (n1 > 0 && (!oct1 || !desc1 || !prev_matched_xy || !matches12 || (check_ori && !angle1))) ||
+        (check_ori && f2->n > 0 && !angle2))
+        return ccm_fail(c, CCM_E_ARG, "bad SearchForInitialization arguments");
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || f2->n == 0) return 0;
+    CCM_HIP(c, hipSetDevice(c->device));
+    std::vector<float> qx(n1), qy(n1), qr(n1); std::vector<int32_t> minl(n1), maxl(n1);
+    for (int i = 0; i < n1; i++) {
+        qx[i] = prev_matched_xy[2 * i]; qy[i] = prev_matched_xy[2 * i + 1];
+        qr[i] = oct1[i] > 0 ? -1.f : (float)window;                             // :464-466 only level-0 features
+        minl[i] = oct1[i]; maxl[i] = oct1[i];
+    }
+    int cap = 128;
+    std::vector<int32_t> ci, cd, cn;
+    for (;;) {
+        int rc = window_candidates(c, f2, n1, qx.data(), qy.data(), qr.data(), minl.data(), maxl.data(), desc1, cap, ci, cd, cn);
+        if (rc) return rc;
+        int mx = 0;
+        for (int k : cn) mx = std::max(mx, k);
+        if (mx <= cap) break;
+        cap = mx;
+    }
+    const int HISTO = 30;
+    std::vector<int> rot[HISTO];
+    const float factor = 1.0f / HISTO;
+    std::vector<int> matched_dist(f2->n, INT32_MAX), m21(f2->n, -1);
+    int nmatches = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (oct1[i1] > 0 || cn[i1] == 0) continue;
+        int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+        for (int k = 0; k < cn[i1]; k++) {
+            const int i2 = ci[(size_t)i1 * cap + k], dist = cd[(size_t)i1 * cap + k];
+            if (matched_dist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= 50) {                                                   // TH_LOW
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (m21[bestIdx2] >= 0) { matches12[m21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2; m21[bestIdx2] = i1; matched_dist[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_ori) {
+                    float r = angle1[i1] - angle2[bestIdx2];
+                    if (r < 0.0) r += 360.0f;
+                    int bin = (int)std::round(r * factor);
+                    if (bin == HISTO) bin = 0;
+                    rot[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_ori) {
+        int a1, a2, a3;
+        three_maxima(rot, HISTO, a1, a2, a3);
+        for (int b = 0; b < HISTO; b++) {
+            if (b == a1 || b == a2 || b == a3) continue;
+            for (int idx1 : rot[b]) if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) { prev_matched_xy[2 * i1] = f2->kp_x[matches12[i1]]; prev_matched_xy[2 * i1 + 1] = f2->kp_y[matches12[i1]]; }
     return nmatches;
 }
 

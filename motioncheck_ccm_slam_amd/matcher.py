@@ -144,3 +144,19 @@ def _search_by_projection_frame(self, cur: FrameGridView, cur_angle, scale_facto
 
 
 ORBmatcher.SearchByProjectionFrame = _search_by_projection_frame
+
+
+def _search_for_initialization(self, oct1, desc1, angle1, f2: FrameGridView, angle2, prev_matched, window: int = 100):
+    """ORBmatcher::SearchForInitialization (ORBmatcher.cpp:448-563).  Returns (nmatches, matches12, prev_matched)."""
+    a = np.ascontiguousarray
+    o1 = a(oct1, "i4"); d1 = a(desc1, np.uint8); a1 = a(angle1, "f4"); a2 = a(angle2, "f4")
+    pm = a(prev_matched, "f4").copy()
+    m12 = np.full(max(len(o1), 1), -1, "i4")
+    g = f2.struct()
+    p = _lib.ptr
+    n = self.ctx.check(self.lib.ccm_search_for_initialization(self.ctx.handle, len(o1), p(o1), p(d1), p(a1), C.byref(g), p(a2), p(pm), int(window),
+                                                              C.c_float(self.mfNNratio), int(self.mbCheckOrientation), p(m12)))
+    return n, m12[:len(o1)], pm
+
+
+ORBmatcher.SearchForInitialization = _search_for_initialization

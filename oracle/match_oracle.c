@@ -288,3 +288,65 @@ int orc_search_by_projection_frame(int n, const float* kx, const float* ky, cons
     free(cand); free(hist); grid_free(g);
     return nmatches;
 }
+
+/* ORBmatcher::SearchForInitialization (ORBmatcher.cpp:448-563).  prev_matched (in/out) = vbPrevMatched. */
+int orc_search_for_initialization(int n1, const int32_t* oct1, const uint8_t* desc1, const float* angle1,
+                                  int n2, const float* kx2, const float* ky2, const int32_t* oct2, const uint8_t* desc2, const float* angle2,
+                                  float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
+                                  float* prev_matched_xy, int window, float nnratio, int check_ori, int32_t* matches12)
+{
+    enum { HISTO = 30 };
+    orc_grid* g = grid_build(n2, kx2, ky2, min_x, min_y, inv_w, inv_h, cols, rows);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n2 > 0 ? n2 : 1));
+    int* matched_dist = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int* m21 = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int32_t* hist = (int32_t*)malloc(sizeof(int32_t) * HISTO * (size_t)(n1 > 0 ? n1 : 1));
+    int32_t hn[HISTO]; memset(hn, 0, sizeof hn);
+    for (int i = 0; i < n2; i++) { matched_dist[i] = 2147483647; m21[i] = -1; }
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    const float factor = 1.0f / HISTO;
+    int nmatches = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = oct1[i1];
+        if (level1 > 0) continue;
+        const int nc = features_in_area(g, kx2, ky2, oct2, prev_matched_xy[2 * i1], prev_matched_xy[2 * i1 + 1], (float)window, level1, level1, cand, n2);
+        if (nc == 0) continue;
+        int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+        for (int k = 0; k < nc; k++) {
+            const int i2 = cand[k];
+            const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+            if (matched_dist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= 50) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (m21[bestIdx2] >= 0) { matches12[m21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2; m21[bestIdx2] = i1; matched_dist[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_ori) {
+                    float rot = angle1[i1] - angle2[bestIdx2];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO) bin = 0;
+                    hist[bin * (size_t)n1 + hn[bin]++] = i1;
+                }
+            }
+        }
+    }
+    if (check_ori) {
+        int32_t ind[3];
+        orc_three_maxima(hn, HISTO, ind);
+        for (int b = 0; b < HISTO; b++) {
+            if (b == ind[0] || b == ind[1] || b == ind[2]) continue;
+            for (int j = 0; j < hn[b]; j++) {
+                const int idx1 = hist[b * (size_t)n1 + j];
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) { prev_matched_xy[2 * i1] = kx2[matches12[i1]]; prev_matched_xy[2 * i1 + 1] = ky2[matches12[i1]]; }
+    free(cand); free(matched_dist); free(m21); free(hist); grid_free(g);
+    return nmatches;
+}

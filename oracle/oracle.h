@@ -75,6 +75,11 @@ int  orc_search_by_projection_frame(int n, const float* kx, const float* ky, con
                                     const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
                                     uint8_t* occupied, float th, int check_ori, int32_t* match);
 
+int  orc_search_for_initialization(int n1, const int32_t* oct1, const uint8_t* desc1, const float* angle1,
+                                   int n2, const float* kx2, const float* ky2, const int32_t* oct2, const uint8_t* desc2, const float* angle2,
+                                   float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
+                                   float* prev_matched_xy, int window, float nnratio, int check_ori, int32_t* matches12);
+
 /* ---- bundle adjustment ---- */
 typedef struct {
     int n_poses; double* poses; const uint8_t* fixed; const double* intr;

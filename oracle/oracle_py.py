@@ -242,3 +242,15 @@ def search_by_projection_frame(kx, ky, octv, desc, angle, min_x, min_y, inv_w, i
                                              C.c_float(inv_w), C.c_float(inv_h), cols, rows, _p(sf), len(va), _p(va), _p(u), _p(v), _p(lo),
                                              _p(la), _p(md), _p(ho), _p(occ), C.c_float(th), int(check_ori), _p(match))
     return n, match[:len(kx)].copy(), occ
+
+
+def search_for_initialization(oct1, desc1, angle1, kx2, ky2, oct2, desc2, angle2, min_x, min_y, inv_w, inv_h, prev_matched, window,
+                              nnratio, check_ori, cols=75, rows=48):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    o1 = a(oct1, "i4"); d1 = a(desc1, np.uint8); a1 = a(angle1, "f4")
+    kx2 = a(kx2, "f4"); ky2 = a(ky2, "f4"); o2 = a(oct2, "i4"); d2 = a(desc2, np.uint8); a2 = a(angle2, "f4")
+    pm = a(prev_matched, "f4").copy(); m12 = np.full(max(len(o1), 1), -1, "i4")
+    n = lib().orc_search_for_initialization(len(o1), _p(o1), _p(d1), _p(a1), len(kx2), _p(kx2), _p(ky2), _p(o2), _p(d2), _p(a2),
+                                            C.c_float(min_x), C.c_float(min_y), C.c_float(inv_w), C.c_float(inv_h), cols, rows,
+                                            _p(pm), int(window), C.c_float(nnratio), int(check_ori), _p(m12))
+    return n, m12[:len(o1)].copy(), pm

@@ -91,3 +91,19 @@ def test_search_by_projection_frame_to_frame(ctx, oracle, check_ori):
                                                              sf, valid, u, v, k1["octave"], k1["angle"], d1, has_obs, occupied, th, check_ori)
         assert nm == rn and (match == rmatch).all() and (occ == rocc).all()
         assert nm > 200
+
+
+def test_search_for_initialization(ctx, oracle):
+    """Monocular initialisation matcher: frame 3 against a shifted copy, window 100 px, level-0 features only."""
+    ex = ORBextractor(2000, 1.2, 8, 20, 7, ctx=ctx)                # the initialisation extractor has 2x features
+    img = synth.frame(3)
+    k1, d1 = ex(img); k2, d2 = ex(np.roll(img, (6, 9), axis=(0, 1)))
+    f2 = FrameGridView(k2["x"], k2["y"], k2["octave"], d2)
+    prev = np.stack([k1["x"], k1["y"]], 1)
+    for ori in (True, False):
+        m = ORBmatcher(0.9, ori, ctx=ctx)
+        nm, m12, pm = m.SearchForInitialization(k1["octave"], d1, k1["angle"], f2, k2["angle"], prev, 100)
+        rn, rm12, rpm = oracle.search_for_initialization(k1["octave"], d1, k1["angle"], f2.kx, f2.ky, f2.oct, d2, k2["angle"], f2.min_x, f2.min_y,
+                                                         f2.inv_w, f2.inv_h, prev, 100, 0.9, ori)
+        assert nm == rn and (m12 == rm12).all() and (pm == rpm).all()
+        assert nm > 100 and (m12[k1["octave"] > 0] == -1).all()

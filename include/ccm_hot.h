@@ -217,6 +217,14 @@ int ccm_search_for_initialization(ccm_ctx*, int n1, const int32_t* oct1, const u
                                   const ccm_frame_grid* f2, const float* angle2, float* prev_matched_xy, int window,
                                   float nnratio, int check_ori, int32_t* matches12);
 
+/* Selection loop of ORBmatcher::Fuse, both overloads (ORBmatcher.cpp:914-955 with the chi2 gate, :1072-1100 without):
+ * per map point that passed the caller's geometric checks (valid, projection u,v, predicted level) the most similar
+ * keyframe feature in the window th * scaleFactor[level] at level-1..level.  best_idx[m] = feature or -1 (bestDist
+ * > TH_LOW); the caller applies Replace / AddObservation in map-point order as :958-990 / :1103-1118. */
+int ccm_fuse_select(ccm_ctx*, const ccm_frame_grid* kf, const float* scale_factors, const float* inv_level_sigma2, int n_mp,
+                    const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, float th,
+                    int chi2_check, int32_t* best_idx, int32_t* best_dist);
+
 /* ---------------------------------------------------------------- optimizer
  * The 6-DoF pose / 3-DoF point reprojection BA that Optimizer::BundleAdjustmentClient
  * (src/Optimizer.cpp:32-212), LocalBundleAdjustmentClient (:349-644) and

@@ -497,4 +497,50 @@ int ccm_search_for_initialization(ccm_ctx* c, int n1, const int32_t* oct1, const
     return nmatches;
 }
 
+// Selection loop of ORBmatcher::Fuse, both overloads (ORBmatcher.cpp:914-955 and :1072-1100)
+int ccm_fuse_select(ccm_ctx* c, const ccm_frame_grid* kf, const float* scale_factors, const float* inv_level_sigma2, int n_mp,
+                    const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, float th,
+                    int chi2_check, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c || !kf) return CCM_E_ARG;
+    if (n_mp < 0 || kf->n < 0 || (n_mp > 0 && (!valid || !u || !v || !level || !mp_desc || !best_idx || !best_dist || !scale_factors)) ||
+        (chi2_check && !inv_level_sigma2))
+        return ccm_fail(c, CCM_E_ARG, "bad Fuse arguments");
+    for (int m = 0; m < n_mp; m++) { best_idx[m] = -1; best_dist[m] = 256; }
+    if (n_mp == 0 || kf->n == 0) return CCM_OK;
+    CCM_HIP(c, hipSetDevice(c->device));
+    std::vector<float> qr(n_mp); std::vector<int32_t> none(n_mp, -1);
+    for (int m = 0; m < n_mp; m++) qr[m] = valid[m] ? th * scale_factors[level[m]] : -1.f;       // :909 / :1068
+    int cap = 64;
+    std::vector<int32_t> ci, cd, cn;
+    for (;;) {
+        int rc = window_candidates(c, kf, n_mp, u, v, qr.data(), none.data(), none.data(), mp_desc, cap, ci, cd, cn);
+        if (rc) return rc;
+        int mx = 0;
+        for (int k : cn) mx = std::max(mx, k);
+        if (mx <= cap) break;
+        cap = mx;
+    }
+    for (int m = 0; m < n_mp; m++) {
+        if (!valid[m]) continue;
+        const int lvl = level[m];
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < cn[m]; k++) {
+            const int idx = ci[(size_t)m * cap + k];
+            const int kpLevel = kf->kp_octave[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            if (chi2_check) {
+                const float ex = u[m] - kf->kp_x[idx], ey = v[m] - kf->kp_y[idx];
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = cd[(size_t)m * cap + k];
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_dist[m] = bestDist;
+        if (bestDist <= 50) best_idx[m] = bestIdx;                              // TH_LOW
+    }
+    return CCM_OK;
+}
+
 }  // extern "C"

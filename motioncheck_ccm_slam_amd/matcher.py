@@ -160,3 +160,20 @@ def _search_for_initialization(self, oct1, desc1, angle1, f2: FrameGridView, ang
 
 
 ORBmatcher.SearchForInitialization = _search_for_initialization
+
+
+def _fuse_select(self, kf: FrameGridView, scale_factors, inv_level_sigma2, valid, u, v, level, mp_desc, th: float, chi2_check: bool):
+    """Selection loop of ORBmatcher::Fuse (both overloads).  Returns (best_idx, best_dist) per map point."""
+    a = np.ascontiguousarray
+    sf = a(scale_factors, "f4"); s2 = a(inv_level_sigma2, "f4"); va = a(valid, np.uint8); uu = a(u, "f4"); vv = a(v, "f4")
+    lv = a(level, "i4"); md = a(mp_desc, np.uint8)
+    n = len(va)
+    bi = np.full(max(n, 1), -1, "i4"); bd = np.full(max(n, 1), 256, "i4")
+    g = kf.struct()
+    p = _lib.ptr
+    self.ctx.check(self.lib.ccm_fuse_select(self.ctx.handle, C.byref(g), p(sf), p(s2), n, p(va), p(uu), p(vv), p(lv), p(md), C.c_float(th),
+                                            int(chi2_check), p(bi), p(bd)))
+    return bi[:n], bd[:n]
+
+
+ORBmatcher.FuseSelect = _fuse_select

@@ -350,3 +350,38 @@ int orc_search_for_initialization(int n1, const int32_t* oct1, const uint8_t* de
     free(cand); free(matched_dist); free(m21); free(hist); grid_free(g);
     return nmatches;
 }
+
+/* Selection loop of ORBmatcher::Fuse (ORBmatcher.cpp:914-955 with the chi2 test, :1072-1100 without): per map point
+ * the most similar keyframe feature inside the window, at level nPredictedLevel-1 or nPredictedLevel.
+ * best_idx = -1 unless bestDist <= TH_LOW. */
+void orc_fuse_select(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
+                     float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                     const float* inv_level_sigma2, int n_mp, const uint8_t* valid, const float* u, const float* v,
+                     const int32_t* level, const uint8_t* mp_desc, float th, int chi2_check, int32_t* best_idx, int32_t* best_dist)
+{
+    orc_grid* g = grid_build(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    for (int m = 0; m < n_mp; m++) {
+        best_idx[m] = -1; best_dist[m] = 256;
+        if (!valid[m]) continue;
+        const int lvl = level[m];
+        const float radius = th * scale_factors[lvl];
+        const int nc = features_in_area(g, kx, ky, oct, u[m], v[m], radius, -1, -1, cand, n);
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            const int kpLevel = oct[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            if (chi2_check) {
+                const float ex = u[m] - kx[idx], ey = v[m] - ky[idx];
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)m, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_dist[m] = bestDist;
+        if (bestDist <= 50) best_idx[m] = bestIdx;
+    }
+    free(cand); grid_free(g);
+}

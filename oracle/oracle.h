@@ -80,6 +80,11 @@ int  orc_search_for_initialization(int n1, const int32_t* oct1, const uint8_t* d
                                    float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
                                    float* prev_matched_xy, int window, float nnratio, int check_ori, int32_t* matches12);
 
+void orc_fuse_select(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
+                     float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                     const float* inv_level_sigma2, int n_mp, const uint8_t* valid, const float* u, const float* v,
+                     const int32_t* level, const uint8_t* mp_desc, float th, int chi2_check, int32_t* best_idx, int32_t* best_dist);
+
 /* ---- bundle adjustment ---- */
 typedef struct {
     int n_poses; double* poses; const uint8_t* fixed; const double* intr;

@@ -254,3 +254,14 @@ def search_for_initialization(oct1, desc1, angle1, kx2, ky2, oct2, desc2, angle2
                                             C.c_float(min_x), C.c_float(min_y), C.c_float(inv_w), C.c_float(inv_h), cols, rows,
                                             _p(pm), int(window), C.c_float(nnratio), int(check_ori), _p(m12))
     return n, m12[:len(o1)].copy(), pm
+
+
+def fuse_select(kx, ky, octv, desc, min_x, min_y, inv_w, inv_h, scale_factors, inv_level_sigma2, valid, u, v, level, mp_desc, th, chi2_check,
+                cols=75, rows=48):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    kx = a(kx, "f4"); ky = a(ky, "f4"); octv = a(octv, "i4"); desc = a(desc, np.uint8); sf = a(scale_factors, "f4"); s2 = a(inv_level_sigma2, "f4")
+    va = a(valid, np.uint8); u = a(u, "f4"); v = a(v, "f4"); lv = a(level, "i4"); md = a(mp_desc, np.uint8)
+    n = len(va); bi = np.full(max(n, 1), -1, "i4"); bd = np.full(max(n, 1), 256, "i4")
+    lib().orc_fuse_select(len(kx), _p(kx), _p(ky), _p(octv), _p(desc), C.c_float(min_x), C.c_float(min_y), C.c_float(inv_w), C.c_float(inv_h),
+                          cols, rows, _p(sf), _p(s2), n, _p(va), _p(u), _p(v), _p(lv), _p(md), C.c_float(th), int(chi2_check), _p(bi), _p(bd))
+    return bi[:n].copy(), bd[:n].copy()

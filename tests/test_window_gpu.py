@@ -107,3 +107,25 @@ def test_search_for_initialization(ctx, oracle):
                                                          f2.inv_w, f2.inv_h, prev, 100, 0.9, ori)
         assert nm == rn and (m12 == rm12).all() and (pm == rpm).all()
         assert nm > 100 and (m12[k1["octave"] > 0] == -1).all()
+
+
+@pytest.mark.parametrize("chi2", [True, False])
+def test_fuse_select(ctx, oracle, chi2):
+    fr, sf, kps, desc = _frame(ctx, 4)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+    is2 = ex.GetInverseScaleSigmaSquares()
+    n = len(fr.kx)
+    rng = np.random.default_rng(8)
+    src = rng.integers(0, n, 900)
+    flips = np.packbits(rng.random((900, 256)) < 0.04, axis=1, bitorder="little")
+    mp_desc = np.concatenate([desc[src] ^ flips, rng.integers(0, 256, (200, 32), dtype=np.uint8)])
+    u = np.concatenate([fr.kx[src] + rng.normal(0, 1.2, 900), rng.uniform(0, 752, 200)]).astype("f4")
+    v = np.concatenate([fr.ky[src] + rng.normal(0, 1.2, 900), rng.uniform(0, 480, 200)]).astype("f4")
+    level = np.concatenate([np.clip(fr.oct[src] + rng.integers(0, 2, 900), 0, 7), rng.integers(0, 8, 200)])
+    valid = rng.random(1100) < 0.9
+    m = ORBmatcher(ctx=ctx)
+    for th in (3.0, 4.0):
+        bi, bd = m.FuseSelect(fr, sf, is2, valid, u, v, level, mp_desc, th, chi2)
+        rbi, rbd = oracle.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, valid, u, v, level, mp_desc, th, chi2)
+        assert (bi == rbi).all() and (bd == rbd).all()
+        assert (bi[:900] >= 0).sum() > 400 and (bi[~valid] == -1).all()

@@ -15,6 +15,10 @@
 
 #define WAVE 64
 
+typedef unsigned short fc_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fc_us2 fc_pk(unsigned x) { return __builtin_bit_cast(fc_us2, x); }
+__device__ __forceinline__ unsigned fc_u(fc_us2 x) { return __builtin_bit_cast(unsigned, x); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
@@ -37,26 +41,42 @@ __device__ __forceinline__ int wave_sum(int v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pyr_resize: one thread = 4 horizontally adjacent output pixels of one row.
+// k_pyr_resize: one thread = 4 horizontally adjacent output pixels in each of RS_ROWS consecutive rows: the x tables
+// are loaded once, and the 2 * RS_ROWS source loads are independent and issued together (the kernel is bound by
+// dependent-load latency, not by bytes or ALU).
 // Fixed-point bilinear exactly as cv::resize(INTER_LINEAR) for 8-bit data:
 // weights are the host-made 11-bit tables, horizontal pass int32, vertical pass
 // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.
+#define RS_ROWS 4
 __global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom g, int level)
 {
     const OrbLevel& D = g.lv[level];
     const OrbLevel& S = g.lv[level - 1];
-    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int x4 = (blockIdx.x * 64 + lane) * 4;
+    // everything that depends on the row only is wave-uniform: kept in scalar registers
+    const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RS_ROWS;
     const int f = blockIdx.z;
-    if (y >= D.h || x4 >= D.w) return;
+    if (yb >= D.h) return;
     const uint8_t* src = S.img + (long long)f * S.plane;
-    uint8_t* dst = const_cast<uint8_t*>(D.img) + (long long)f * D.plane + (long long)y * D.pitch;
-    const int sy0 = D.yofs[y];
-    const int sy1 = min(sy0 + 1, S.h - 1);
-    const int b0 = D.yab[2 * y], b1 = D.yab[2 * y + 1];
-    const uint8_t* r0p = src + (long long)sy0 * S.pitch;
-    const uint8_t* r1p = src + (long long)sy1 * S.pitch;
-    unsigned out = 0;
+    uint8_t* dstp = const_cast<uint8_t*>(D.img) + (long long)f * D.plane;
+    // lanes 0..RS_ROWS-1 fetch the y tables of the wave's rows; v_readlane broadcasts them
+    int yo; unsigned ybb;
+    {
+        const int y = min(yb + (lane & (RS_ROWS - 1)), D.h - 1);
+        yo = D.yofs[y];
+        __builtin_memcpy(&ybb, D.yab + 2 * y, 4);
+    }
+    const uint8_t* r0p[RS_ROWS]; const uint8_t* r1p[RS_ROWS]; unsigned b0[RS_ROWS], b1[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int sy0 = __builtin_amdgcn_readlane(yo, r);
+        const unsigned bb = (unsigned)__builtin_amdgcn_readlane((int)ybb, r);
+        r0p[r] = src + (long long)sy0 * S.pitch;
+        r1p[r] = src + (long long)min(sy0 + 1, S.h - 1) * S.pitch;
+        b0[r] = bb & 0xFFFFu; b1[r] = bb >> 16;
+    }
+    if (x4 >= D.w) return;
     if (x4 + 3 < D.w) {
         // tables of the 4 outputs in two 16-byte loads
         int4 so; uint4 ab;                                   // tables are only 4-/2-byte aligned
@@ -65,39 +85,59 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom g, int level)
         const int sxs[4] = { so.x, so.y, so.z, so.w };
         const unsigned abw[4] = { ab.x, ab.y, ab.z, ab.w };
         const int base = so.x;
-        if (so.w + 1 - base < 8 && base + 8 <= S.w) {
-            // the 4 outputs read source columns base .. base+7 at most: two unaligned 8-byte loads
-            unsigned long long q0, q1;
-            __builtin_memcpy(&q0, r0p + base, 8);
-            __builtin_memcpy(&q1, r1p + base, 8);
+        const unsigned ba = (unsigned)(base & ~3);
+        if (so.w + 1 - base < 8 && base + 8 <= S.w && (int)ba + 12 <= S.pitch) {
+            // the 4 outputs read source columns base .. base+7 at most: three aligned dwords per source row,
+            // shifted into place by v_alignbyte
+            uint2 q0[RS_ROWS], q1[RS_ROWS];
+            const unsigned sh = (unsigned)(base & 3);
+#pragma unroll
+            for (int r = 0; r < RS_ROWS; r++) {
+                const unsigned* p0 = reinterpret_cast<const unsigned*>(r0p[r] + ba);
+                const unsigned* p1 = reinterpret_cast<const unsigned*>(r1p[r] + ba);
+                const unsigned d00 = p0[0], d01 = p0[1], d02 = p0[2], d10 = p1[0], d11 = p1[1], d12 = p1[2];
+                q0[r].x = __builtin_amdgcn_alignbyte(d01, d00, sh); q0[r].y = __builtin_amdgcn_alignbyte(d02, d01, sh);
+                q1[r].x = __builtin_amdgcn_alignbyte(d11, d10, sh); q1[r].y = __builtin_amdgcn_alignbyte(d12, d11, sh);
+            }
+            unsigned sel[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int o = sxs[i] - base;
-                const int a0 = (short)(abw[i] & 0xFFFFu), a1 = (short)(abw[i] >> 16);
-                const int p00 = (int)((q0 >> (8 * o)) & 0xFF), p01 = (int)((q0 >> (8 * o + 8)) & 0xFF);
-                const int p10 = (int)((q1 >> (8 * o)) & 0xFF), p11 = (int)((q1 >> (8 * o + 8)) & 0xFF);
-                const int r0 = p00 * a0 + p01 * a1;
-                const int r1 = p10 * a0 + p11 * a1;
-                const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                out |= (unsigned)(v & 255) << (8 * i);
+                const unsigned o = (unsigned)(sxs[i] - base);
+                sel[i] = 0x0c010c00u + o + (o << 16);       // v_perm_b32: bytes o and o+1 as a u16 pair
             }
-            *reinterpret_cast<unsigned*>(dst + x4) = out;
+#pragma unroll
+            for (int r = 0; r < RS_ROWS; r++) {
+                unsigned out = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    // v_dot2_u32_u16 applies the packed (a0,a1) weights
+                    const unsigned h0 = __builtin_amdgcn_udot2(fc_pk(__builtin_amdgcn_perm(q0[r].y, q0[r].x, sel[i])), fc_pk(abw[i]), 0u, false);
+                    const unsigned h1 = __builtin_amdgcn_udot2(fc_pk(__builtin_amdgcn_perm(q1[r].y, q1[r].x, sel[i])), fc_pk(abw[i]), 0u, false);
+                    // b <= 2048 and h >> 4 < 2^15: 24-bit multiplies are exact; the result is <= 255
+                    const unsigned v = ((__umul24(b0[r], h0 >> 4) >> 16) + (__umul24(b1[r], h1 >> 4) >> 16) + 2u) >> 2;
+                    out |= v << (8 * i);
+                }
+                if (yb + r < D.h) *reinterpret_cast<unsigned*>(dstp + (long long)(yb + r) * D.pitch + (unsigned)x4) = out;
+            }
             return;
         }
     }
+    for (int r = 0; r < RS_ROWS && yb + r < D.h; r++) {
+        unsigned out = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int x = min(x4 + i, D.w - 1);
-        const int sx0 = D.xofs[x];
-        const int sx1 = min(sx0 + 1, S.w - 1);
-        const int a0 = D.xab[2 * x], a1 = D.xab[2 * x + 1];
-        const int r0 = r0p[sx0] * a0 + r0p[sx1] * a1;
-        const int r1 = r1p[sx0] * a0 + r1p[sx1] * a1;
-        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        out |= (unsigned)(v & 255) << (8 * i);
+        for (int i = 0; i < 4; i++) {
+            const int x = min(x4 + i, D.w - 1);
+            const int sx0 = D.xofs[x];
+            const int sx1 = min(sx0 + 1, S.w - 1);
+            const int a0 = D.xab[2 * x], a1 = D.xab[2 * x + 1];
+            const int h0 = r0p[r][sx0] * a0 + r0p[r][sx1] * a1;
+            const int h1 = r1p[r][sx0] * a0 + r1p[r][sx1] * a1;
+            const int v = ((((int)b0[r] * (h0 >> 4)) >> 16) + (((int)b1[r] * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= (unsigned)(v & 255) << (8 * i);
+        }
+        // our level buffers have pitch % 64 == 0 and a 256-byte aligned base: the dword store is aligned
+        *reinterpret_cast<unsigned*>(dstp + (long long)(yb + r) * D.pitch + (unsigned)x4) = out;
     }
-    // our level buffers have pitch % 64 == 0 and a 256-byte aligned base: the dword store is aligned
-    *reinterpret_cast<unsigned*>(dst + x4) = out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,6 +385,10 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 // the survivor list holds `surv_cap` pixels; the detection rows are processed in blocks of surv_cap / pitch rows
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap) { return 2 * (size_t)pitch * bh + (size_t)surv_cap * 2 + 32; }
 
+
+// PACKED: the rejection test on two pixels per register with the packed 16-bit VALU (v_pk_sub_u16 / v_pk_max_u16 /
+// v_pk_min_u16): |v - n| <= t  <=>  (u16)(v + t - n) <= 2t.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
                                                     unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV)
 {
@@ -395,7 +439,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
             const int row = r0 + rr, dw = it - rr * PW;
             const int px = 4 * dw;
             unsigned keep4 = 0;
-            if (it < items && px + 3 >= c_lo && px < c_hi && dw >= 1 && dw + 1 < PW) {
+            if (!PACKED && it < items && px + 3 >= c_lo && px < c_hi && dw >= 1 && dw + 1 < PW) {
                 const unsigned* crow = reinterpret_cast<const unsigned*>(T + row * P) + dw;
                 const unsigned c0 = crow[-1], c1 = crow[0], c2 = crow[1];
                 const unsigned nn = reinterpret_cast<const unsigned*>(T + (row + 3) * P)[dw];
@@ -411,6 +455,32 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
                     const int e = (int)((hi >> (8 * (i + 3))) & 0xFF);         // column col+3 = byte 4+i+3
                     const bool keep = !((abs(v - n) <= t_lo && abs(v - s2) <= t_lo) || (abs(v - e) <= t_lo && abs(v - w) <= t_lo));
                     keep4 |= keep ? (1u << i) : 0u;
+                }
+            }
+            if (PACKED && it < items && px + 3 >= c_lo && px < c_hi && dw >= 1 && dw + 1 < PW) {
+                const unsigned* crow = reinterpret_cast<const unsigned*>(T + row * P) + dw;
+                const unsigned c0 = crow[-1], c1 = crow[0], c2 = crow[1];
+                const unsigned nn = reinterpret_cast<const unsigned*>(T + (row + 3) * P)[dw];
+                const unsigned ss = reinterpret_cast<const unsigned*>(T + (row - 3) * P)[dw];
+                const unsigned ww = __builtin_amdgcn_alignbyte(c1, c0, 1);        // columns px-3 .. px
+                const unsigned ee = __builtin_amdgcn_alignbyte(c2, c1, 3);        // columns px+3 .. px+6
+                const unsigned M = 0x00FF00FFu;
+                const unsigned tt = (unsigned)t_lo * 0x00010001u;
+                const fc_us2 t2 = fc_pk(2u * tt);
+                unsigned kk[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {                                     // h = 0: pixels 0 and 2; h = 1: pixels 1 and 3
+                    const fc_us2 vt = fc_pk(((c1 >> (8 * h)) & M) + tt);
+                    const fc_us2 xn = vt - fc_pk((nn >> (8 * h)) & M), xs = vt - fc_pk((ss >> (8 * h)) & M);
+                    const fc_us2 xw = vt - fc_pk((ww >> (8 * h)) & M), xe = vt - fc_pk((ee >> (8 * h)) & M);
+                    const fc_us2 m = __builtin_elementwise_min(__builtin_elementwise_max(xn, xs), __builtin_elementwise_max(xe, xw));
+                    kk[h] = fc_u(__builtin_elementwise_sub_sat(m, t2));           // != 0 per half  <=>  not rejected
+                }
+                if ((kk[0] | kk[1]) != 0u) {
+                    keep4 = ((kk[0] & 0xFFFFu) ? 1u : 0u) | ((kk[1] & 0xFFFFu) ? 2u : 0u) | ((kk[0] >> 16) ? 4u : 0u) | ((kk[1] >> 16) ? 8u : 0u);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (px + i < c_lo || px + i >= c_hi) keep4 &= ~(1u << i);
                 }
             }
             if (__ballot(keep4 != 0u) != 0ull) {               // survivors are rare: one ballot decides for the wave
@@ -1022,7 +1092,7 @@ size_t orb_octree_lds_bytes(int list_cap) { return (size_t)list_cap * OCT_NODE_L
 
 void orb_launch_resize(hipStream_t s, const OrbGeom& g_dev, int level, int dw, int dh, int nframes)
 {
-    dim3 grid((dw + 255) / 256, (dh + 3) / 4, nframes);
+    dim3 grid((dw + 255) / 256, (dh + 4 * RS_ROWS - 1) / (4 * RS_ROWS), nframes);
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, g_dev, level);
 }
 void orb_launch_score(hipStream_t s, const OrbGeom& g_dev, int ntiles, int nframes)
@@ -1037,7 +1107,9 @@ void orb_launch_nms(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, i
 void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, const OrbBand* bands, int nbands, int nframes,
                            size_t lds_bytes, int surv_cap, unsigned* slots, int* cell_count)
 {
-    hipLaunchKernelGGL(k_fast_cells, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap);
+    static const bool packed = !(getenv("CCM_FC_PACKED") && atoi(getenv("CCM_FC_PACKED")) == 0);
+    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap);
+    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap);
 }
 size_t orb_fast_cells_lds(int pitch, int bh, int surv_cap) { return fc_lds_bytes(pitch, bh, surv_cap); }
 void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,

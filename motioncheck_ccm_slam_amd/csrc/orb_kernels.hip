@@ -427,6 +427,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     const int c_lo = cfirst.x0 + 3 - B.xa, c_hi = clast.x0 + clast.cw - 3 - B.xa;
     const int t_lo = min(g.ini_th, g.min_th);
     const int RB = max(1, FC_SURV / P);                      // rows per block: at most FC_SURV pixels
+    // dwords that hold at least one detection column and have both neighbours inside the row
+    const int dw_lo = max(1, c_lo >> 2);
+    const int dw_hi = min(PW - 2, (c_hi - 1) >> 2);
     __syncthreads();
     for (int r0 = 3; r0 < bh - 3; r0 += RB) {
         if (tid == 0) *nsurv = 0;
@@ -457,24 +460,26 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
                     keep4 |= keep ? (1u << i) : 0u;
                 }
             }
-            if (PACKED && it < items && px + 3 >= c_lo && px < c_hi && dw >= 1 && dw + 1 < PW) {
-                const unsigned* crow = reinterpret_cast<const unsigned*>(T + row * P) + dw;
+            if (PACKED && it < items && dw >= dw_lo && dw <= dw_hi) {
+                // P == 4 * PW: the centre dword of item `it` sits at byte r0 * P + 4 * it
+                const unsigned* crow = reinterpret_cast<const unsigned*>(T + r0 * P) + it;
                 const unsigned c0 = crow[-1], c1 = crow[0], c2 = crow[1];
-                const unsigned nn = reinterpret_cast<const unsigned*>(T + (row + 3) * P)[dw];
-                const unsigned ss = reinterpret_cast<const unsigned*>(T + (row - 3) * P)[dw];
+                const unsigned nn = crow[3 * PW], ss = crow[-3 * PW];
                 const unsigned ww = __builtin_amdgcn_alignbyte(c1, c0, 1);        // columns px-3 .. px
                 const unsigned ee = __builtin_amdgcn_alignbyte(c2, c1, 3);        // columns px+3 .. px+6
-                const unsigned M = 0x00FF00FFu;
-                const unsigned tt = (unsigned)t_lo * 0x00010001u;
-                const fc_us2 t2 = fc_pk(2u * tt);
+                const fc_us2 tt = fc_pk((unsigned)t_lo * 0x00010001u);
                 unsigned kk[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {                                     // h = 0: pixels 0 and 2; h = 1: pixels 1 and 3
-                    const fc_us2 vt = fc_pk(((c1 >> (8 * h)) & M) + tt);
-                    const fc_us2 xn = vt - fc_pk((nn >> (8 * h)) & M), xs = vt - fc_pk((ss >> (8 * h)) & M);
-                    const fc_us2 xw = vt - fc_pk((ww >> (8 * h)) & M), xe = vt - fc_pk((ee >> (8 * h)) & M);
-                    const fc_us2 m = __builtin_elementwise_min(__builtin_elementwise_max(xn, xs), __builtin_elementwise_max(xe, xw));
-                    kk[h] = fc_u(__builtin_elementwise_sub_sat(m, t2));           // != 0 per half  <=>  not rejected
+                    const unsigned sel = h ? 0x0c030c01u : 0x0c020c00u;           // v_perm_b32: two bytes -> two u16
+                    const fc_us2 v = fc_pk(__builtin_amdgcn_perm(0u, c1, sel));
+                    const fc_us2 n = fc_pk(__builtin_amdgcn_perm(0u, nn, sel)), sq = fc_pk(__builtin_amdgcn_perm(0u, ss, sel));
+                    const fc_us2 w = fc_pk(__builtin_amdgcn_perm(0u, ww, sel)), e = fc_pk(__builtin_amdgcn_perm(0u, ee, sel));
+                    // every 9-arc holds ring pixel k or k+8: a corner brighter (darker) than v by more than t needs the
+                    // larger (smaller) of BOTH opposite pairs beyond v + t (v - t)
+                    const fc_us2 bm = __builtin_elementwise_min(__builtin_elementwise_max(n, sq), __builtin_elementwise_max(e, w));
+                    const fc_us2 dm = __builtin_elementwise_max(__builtin_elementwise_min(n, sq), __builtin_elementwise_min(e, w));
+                    kk[h] = fc_u(__builtin_elementwise_sub_sat(bm, (fc_us2)(v + tt))) | fc_u(__builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, tt), dm));
                 }
                 if ((kk[0] | kk[1]) != 0u) {
                     keep4 = ((kk[0] & 0xFFFFu) ? 1u : 0u) | ((kk[1] & 0xFFFFu) ? 2u : 0u) | ((kk[0] >> 16) ? 4u : 0u) | ((kk[1] >> 16) ? 8u : 0u);
@@ -483,19 +488,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
                         if (px + i < c_lo || px + i >= c_hi) keep4 &= ~(1u << i);
                 }
             }
-            if (__ballot(keep4 != 0u) != 0ull) {               // survivors are rare: one ballot decides for the wave
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const bool keep = (keep4 >> i) & 1u;
-                    const unsigned long long m = __ballot(keep);
-                    if (m != 0ull) {
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(nsurv, __popcll(m));
-                        base = __shfl(base, 0, 64);
-                        const int pos = base + __popcll(m & lanemask_lt());
-                        if (keep && pos < FC_SURV) surv[pos] = (unsigned short)(row * P + px + i);
-                    }
-                }
+            if (__ballot(keep4 != 0u) != 0ull) {               // one LDS atomic per wave and item
+                const unsigned long long m0 = __ballot((keep4 & 1u) != 0u), m1 = __ballot((keep4 & 2u) != 0u);
+                const unsigned long long m2 = __ballot((keep4 & 4u) != 0u), m3 = __ballot((keep4 & 8u) != 0u);
+                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(nsurv, n0 + n1 + n2 + n3);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned long long lt = lanemask_lt();
+                const int pos0 = row * P + px;
+                int q;
+                if ((keep4 & 1u) && (q = base + __popcll(m0 & lt)) < FC_SURV) surv[q] = (unsigned short)pos0;
+                if ((keep4 & 2u) && (q = base + n0 + __popcll(m1 & lt)) < FC_SURV) surv[q] = (unsigned short)(pos0 + 1);
+                if ((keep4 & 4u) && (q = base + n0 + n1 + __popcll(m2 & lt)) < FC_SURV) surv[q] = (unsigned short)(pos0 + 2);
+                if ((keep4 & 8u) && (q = base + n0 + n1 + n2 + __popcll(m3 & lt)) < FC_SURV) surv[q] = (unsigned short)(pos0 + 3);
             }
         }
         __syncthreads();

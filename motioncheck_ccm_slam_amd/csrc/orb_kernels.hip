@@ -383,7 +383,15 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 // each cell's threshold choice / 3x3 NMS / ordered compaction runs straight from the LDS score tile: the score
 // map never goes to HBM.  Bands of adjacent cell rows overlap by 6 rows, which are scored twice.
 // the survivor list holds `surv_cap` pixels; the detection rows are processed in blocks of surv_cap / pitch rows
-__host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap) { return 2 * (size_t)pitch * bh + (size_t)surv_cap * 2 + 32; }
+// NMS works on the list of scored pixels (FC_NZ entries) and the list of local maxima (FC_KEPT); a band that overflows
+// either list takes the per-cell row scan instead.
+#define FC_NZ 1024
+#define FC_KEPT 512
+#define FC_CELLS 32
+__host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
+{
+    return 2 * (size_t)pitch * bh + (size_t)surv_cap * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 12;
+}
 
 
 // PACKED: the rejection test on two pixels per register with the packed 16-bit VALU (v_pk_sub_u16 / v_pk_max_u16 /
@@ -400,7 +408,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     uint8_t* T = fc_smem;                                   // pixels  [bh][P]
     uint8_t* S = fc_smem + (size_t)P * bh;                  // scores  [bh][P]
     unsigned short* surv = reinterpret_cast<unsigned short*>(S + (size_t)P * bh);
-    int* nsurv = reinterpret_cast<int*>(surv + FC_SURV);
+    int* nsurv = reinterpret_cast<int*>(surv + FC_SURV);     // [0] survivors of the row block, [1] scored pixels, [2] local maxima
+    unsigned short* nz = reinterpret_cast<unsigned short*>(nsurv + 8);
+    unsigned* kept = reinterpret_cast<unsigned*>(nz + FC_NZ);
+    int* cell_hi = reinterpret_cast<int*>(kept + FC_KEPT);   // per cell: local maxima with score >= iniThFAST
+    int* cell_n = cell_hi + FC_CELLS;                        // per cell: keypoints written
+    short* clo = reinterpret_cast<short*>(cell_n + FC_CELLS); // per cell: first detection column of the tile, and its width
+    short* cwd = clo + FC_CELLS;
+    if (tid < FC_CELLS) {
+        cell_hi[tid] = 0; cell_n[tid] = 0;
+        if (tid < B.ncells) {
+            const OrbCell c = cells[B.cell_first + tid];
+            clo[tid] = (short)(c.x0 + 3 - B.xa); cwd[tid] = (short)(c.cw - 6);
+        }
+    }
+    if (tid == 0) { nsurv[1] = 0; nsurv[2] = 0; }
     const uint8_t* img = L.img + (long long)f * L.plane;
     // ---- stage pixels (clamped: duplicates are only read for pixels whose score is not needed), zero the scores
     const bool dword_ok = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)L.pitch) & 3) == 0 && L.pitch >= ((L.w + 3) & ~3);
@@ -516,9 +538,67 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
             r[8] = c[-3 * P];     r[9] = c[-3 * P - 1]; r[10] = c[-2 * P - 2]; r[11] = c[-P - 3];
             r[12] = c[-3];        r[13] = c[P - 3];     r[14] = c[2 * P - 2]; r[15] = c[3 * P - 1];
             const int sc = fast_score16(v, r);
-            if (sc >= t_lo && sc > 0) S[pos] = (uint8_t)sc;
+            if (sc >= t_lo && sc > 0) {
+                S[pos] = (uint8_t)sc;
+                const int q = atomicAdd(nsurv + 1, 1);
+                if (q < FC_NZ) nz[q] = (unsigned short)pos;
+            }
         }
         __syncthreads();
+    }
+    // ---- NMS on the list of scored pixels.  With minThFAST <= iniThFAST every stored score is >= minThFAST, so
+    // "keep at threshold th" == score >= th and strictly greater than every neighbour inside the cell's rectangle.
+    const int nnz = nsurv[1];
+    const int rh = bh - 6;
+    bool listed = g.min_th <= g.ini_th && nnz <= FC_NZ && B.ncells <= FC_CELLS;
+    if (listed) {
+        for (int e = tid; e < nnz; e += 256) {
+            const int pos = nz[e];
+            const int row = pos / P, col = pos - row * P;
+            int ci = -1;
+            for (int i = 0; i < B.ncells; i++)
+                if (col >= clo[i] && col < clo[i] + cwd[i]) ci = i;
+            if (ci < 0) continue;
+            const int xx = col - clo[ci], yy = row - 3, rw = cwd[ci];
+            const uint8_t* p = S + pos;
+            const int sc = p[0];
+            const bool l = xx > 0, r = xx + 1 < rw, u = yy > 0, d = yy + 1 < rh;
+#define NB(c, o) ((c) ? (int)p[o] : 0)
+            const bool keep = sc > NB(l, -1) && sc > NB(r, 1) &&
+                              sc > NB(u && l, -P - 1) && sc > NB(u, -P) && sc > NB(u && r, -P + 1) &&
+                              sc > NB(d && l, P - 1) && sc > NB(d, P) && sc > NB(d && r, P + 1);
+#undef NB
+            if (keep) {
+                const int q = atomicAdd(nsurv + 2, 1);
+                if (q < FC_KEPT) kept[q] = ((unsigned)ci << 20) | ((unsigned)yy << 14) | ((unsigned)xx << 8) | (unsigned)sc;
+                if (sc >= g.ini_th) atomicAdd(cell_hi + ci, 1);
+            }
+        }
+        __syncthreads();
+        const int nk = nsurv[2];
+        listed = nk <= FC_KEPT;
+        if (listed) {
+            for (int e = tid; e < nk; e += 256) {
+                const unsigned me = kept[e];
+                const int ci = (int)(me >> 20);
+                const unsigned th = (unsigned)(cell_hi[ci] > 0 ? g.ini_th : g.min_th);      // :978-984: ini first, else min
+                if ((me & 255u) < th) continue;
+                int rank = 0;                                                             // row-major order inside the cell
+                for (int k = 0; k < nk; k++) {
+                    const unsigned o = kept[k];
+                    rank += ((int)(o >> 20) == ci && (o & 255u) >= th && (o >> 8) < (me >> 8)) ? 1 : 0;
+                }
+                const OrbCell c = cells[B.cell_first + ci];
+                if (rank < c.slot_cap)
+                    slots[(long long)f * g.slots_per_frame + c.slot_first + rank] =
+                        ((me & 255u) << 24) | ((unsigned)(c.y0 + 3 - ORB_BORDER + (int)((me >> 14) & 63u)) << 12) |
+                        (unsigned)(c.x0 + 3 - ORB_BORDER + (int)((me >> 8) & 63u));
+                atomicAdd(cell_n + ci, 1);
+            }
+            __syncthreads();
+            if (tid < B.ncells) cell_count[(long long)f * g.ncells + B.cell_first + tid] = cell_n[tid];
+            return;
+        }
     }
     // ---- per cell: threshold choice, strict 3x3 NMS inside the cell's detection rectangle, ordered compaction
     for (int ci = wv; ci < B.ncells; ci += 4) {

@@ -204,11 +204,15 @@ int ccm_search_by_projection(ccm_ctx*, const ccm_frame_grid*, const float* scale
  * TrackWithMotionModel.  Per last-frame feature: valid = has a map point, not an outlier, and its projection (u,v)
  * into the current frame (computed by the caller in float as :1382-1393) has positive depth and lies inside the
  * frame bounds; last_octave, last_angle = LastFrame.mvKeys[i].octave / mvKeysUn[i].angle.  match[i2] = last-frame
- * feature whose map point is assigned to current feature i2, or -1.  Returns nmatches. */
+ * feature whose map point is assigned to current feature i2, or -1.  Returns nmatches.  orb_dist = TH_HIGH (100) here.
+ * The relocalisation overload SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1478-1605) is the same
+ * loop over the keyframe's map points: valid = not bad, not in sAlreadyFound and projected inside the frame and the
+ * distance range (:1502-1531), last_octave = nPredictedLevel, last_angle = pKF->mvKeysUn[i].angle, mp_has_obs all 1
+ * (any assigned feature is skipped, :1547), occupied = mvpMapPoints[i2] != null, orb_dist = ORBdist. */
 int ccm_search_by_projection_frame(ccm_ctx*, const ccm_frame_grid* current, const float* cur_angle, const float* scale_factors,
                                    int n_last, const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave,
                                    const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied,
-                                   float th, int check_ori, int32_t* match);
+                                   float th, int check_ori, int orb_dist, int32_t* match);
 
 /* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cpp:448-563).
  * prev_matched_xy [n1][2] is vbPrevMatched (updated for matched features as :556-558); matches12[i1] = index into
@@ -220,10 +224,37 @@ int ccm_search_for_initialization(ccm_ctx*, int n1, const int32_t* oct1, const u
 /* Selection loop of ORBmatcher::Fuse, both overloads (ORBmatcher.cpp:914-955 with the chi2 gate, :1072-1100 without):
  * per map point that passed the caller's geometric checks (valid, projection u,v, predicted level) the most similar
  * keyframe feature in the window th * scaleFactor[level] at level-1..level.  best_idx[m] = feature or -1 (bestDist
- * > TH_LOW); the caller applies Replace / AddObservation in map-point order as :958-990 / :1103-1118. */
+ * > accept_th = TH_LOW); the caller applies Replace / AddObservation in map-point order as :958-990 / :1103-1118. */
 int ccm_fuse_select(ccm_ctx*, const ccm_frame_grid* kf, const float* scale_factors, const float* inv_level_sigma2, int n_mp,
                     const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, float th,
-                    int chi2_check, int32_t* best_idx, int32_t* best_dist);
+                    int chi2_check, int accept_th, int32_t* best_idx, int32_t* best_dist);
+
+/* ORBmatcher::SearchBySim3 (ORBmatcher.cpp:1124-1348).  The caller projects every map point of KF1 into KF2 with the
+ * Sim3 (valid1/u1/v1/level1 per feature of KF1, :1170-1208; mp_desc1 = GetDescriptor()) and vice versa; both
+ * directions select the most similar feature (<= TH_HIGH) and match12[i1] = i2 where they agree (:1330-1345), else -1.
+ * Returns nFound. */
+int ccm_search_by_sim3(ccm_ctx*, const ccm_frame_grid* kf1, const float* scale_factors1, const ccm_frame_grid* kf2, const float* scale_factors2,
+                       const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* mp_desc1,
+                       const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* mp_desc2,
+                       float th, int32_t* match12);
+
+/* ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cpp:308-446), loop closing.  valid/u/v/
+ * level = the caller's projection checks (:333-377); matched[idx] (in/out) = vpMatched[idx] != null; observed[m] = the
+ * point already is an observation of pKF (GetIndexInKeyFrame != -1, :414: the caller re-maps it, vpMatched is not
+ * touched).  best_idx[m] = chosen feature or -1.  Returns nmatches. */
+int ccm_search_by_projection_sim3(ccm_ctx*, const ccm_frame_grid* kf, const float* scale_factors, int n_mp, const uint8_t* valid,
+                                  const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, const uint8_t* observed,
+                                  uint8_t* matched, float th, int32_t* best_idx);
+
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cpp:700-852): per feature of KF1 without a map point, the most
+ * similar (<= TH_LOW, last one among equals) feature of KF2 in the same vocabulary node that has no map point, is
+ * not near the epipole (ex, ey) (:775-777) and fulfils the epipolar constraint of F12 (row-major 3x3 float,
+ * CheckDistEpipolarLine :159-176); rotation-histogram filter when check_ori.  match12[i1] = i2 or -1 (the caller
+ * lists the pairs in i1 order, :843-849).  Returns nmatches. */
+int ccm_search_for_triangulation(ccm_ctx*, const uint8_t* desc1, const int32_t* node1, const uint8_t* has_mp1, const float* x1, const float* y1,
+                                 const float* angle1, int n1, const uint8_t* desc2, const int32_t* node2, const uint8_t* has_mp2,
+                                 const float* x2, const float* y2, const float* angle2, const int32_t* octave2, int n2, const float* F12,
+                                 float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int check_ori, int32_t* match12);
 
 /* ---------------------------------------------------------------- optimizer
  * The 6-DoF pose / 3-DoF point reprojection BA that Optimizer::BundleAdjustmentClient

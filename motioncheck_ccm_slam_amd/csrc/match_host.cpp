@@ -125,28 +125,29 @@ static void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& i
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, const int32_t* node1, const uint8_t* valid1,
-                  const float* angle1, int n1, const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2,
-                  const float* angle2, int n2, int32_t* match12)
+// Side-2 candidates of every side-1 feature = the features of the same vocabulary node (DBoW2::FeatureVector walk of
+// SearchByBoW / SearchForTriangulation), with their Hamming distances from k_hamming_ranges.
+struct BowRanges {
+    std::vector<int> ord1, ord2, start, len;
+    std::vector<long long> off;
+    std::vector<unsigned short> dist;
+};
+static int bow_ranges(ccm_ctx* c, const uint8_t* desc1, const int32_t* node1, const uint8_t* valid1, int n1,
+                      const uint8_t* desc2, const int32_t* node2, int n2, BowRanges& R)
 {
-    if (!c || !o) return CCM_E_ARG;
-    if (n1 < 0 || n2 < 0 || (n1 > 0 && (!desc1 || !node1 || !valid1 || !match12)) || (n2 > 0 && (!desc2 || !node2)) ||
-        (o->check_ori && n1 > 0 && n2 > 0 && (!angle1 || !angle2)))
-        return ccm_fail(c, CCM_E_ARG, "bad SearchByBoW arguments");
-    for (int i = 0; i < n1; i++) match12[i] = -1;
-    if (n1 == 0 || n2 == 0) return 0;
-    CCM_HIP(c, hipSetDevice(c->device));
     if (!c->match) c->match = new MatchState();
     MatchState& M = *c->match;
+    std::vector<int>&ord1 = R.ord1, &ord2 = R.ord2, &start = R.start, &len = R.len;
+    std::vector<long long>& off = R.off;
+    std::vector<unsigned short>& dist = R.dist;
     // FeatureVector order: node ascending, feature index ascending inside a node (DBoW2 fills it so)
-    std::vector<int> ord1(n1), ord2(n2);
+    ord1.assign(n1, 0); ord2.assign(n2, 0);
     std::iota(ord1.begin(), ord1.end(), 0); std::iota(ord2.begin(), ord2.end(), 0);
     auto by_node = [](const int32_t* node) { return [node](int a, int b) { return node[a] != node[b] ? node[a] < node[b] : a < b; }; };
     std::stable_sort(ord1.begin(), ord1.end(), by_node(node1));
     std::stable_sort(ord2.begin(), ord2.end(), by_node(node2));
     // per side-1 feature: the slice of ord2 holding its node (features without a node have id < 0)
-    std::vector<int> start(n1, 0), len(n1, 0);
-    std::vector<long long> off(n1 + 1, 0);
+    start.assign(n1, 0); len.assign(n1, 0); off.assign(n1 + 1, 0);
     {
         size_t b = 0;
         for (size_t a = 0; a < ord1.size();) {
@@ -160,7 +161,7 @@ int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, co
     }
     for (int i = 0; i < n1; i++) off[i + 1] = off[i] + len[i];
     const long long total = off[n1];
-    std::vector<unsigned short> dist((size_t)std::max<long long>(total, 1));
+    dist.assign((size_t)std::max<long long>(total, 1), 0);
     if (total > 0) {
         CCM_RESERVE(c, M.d1, (size_t)n1 * 32); CCM_RESERVE(c, M.d2, (size_t)n2 * 32);
         CCM_RESERVE(c, M.order2, (size_t)n2 * 4); CCM_RESERVE(c, M.start, (size_t)n1 * 4); CCM_RESERVE(c, M.len, (size_t)n1 * 4);
@@ -177,6 +178,28 @@ int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, co
         CCM_HIP(c, hipMemcpyAsync(dist.data(), M.dist.p, (size_t)total * 2, hipMemcpyDeviceToHost, c->stream));
         CCM_HIP(c, hipStreamSynchronize(c->stream));
     }
+    return CCM_OK;
+}
+
+int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, const int32_t* node1, const uint8_t* valid1,
+                  const float* angle1, int n1, const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2,
+                  const float* angle2, int n2, int32_t* match12)
+{
+    if (!c || !o) return CCM_E_ARG;
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && (!desc1 || !node1 || !valid1 || !match12)) || (n2 > 0 && (!desc2 || !node2)) ||
+        (o->check_ori && n1 > 0 && n2 > 0 && (!angle1 || !angle2)))
+        return ccm_fail(c, CCM_E_ARG, "bad SearchByBoW arguments");
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    CCM_HIP(c, hipSetDevice(c->device));
+    BowRanges R;
+    {
+        int rc = bow_ranges(c, desc1, node1, valid1, n1, desc2, node2, n2, R);
+        if (rc) return rc;
+    }
+    const std::vector<int>&ord1 = R.ord1, &ord2 = R.ord2, &start = R.start, &len = R.len;
+    const std::vector<long long>& off = R.off;
+    const std::vector<unsigned short>& dist = R.dist;
     // greedy acceptance in the reference's visiting order (sequential by construction: a side-2
     // feature matched earlier is skipped later, ORBmatcher.cpp:228-229 / :619)
     const int HISTO = 30;
@@ -365,7 +388,7 @@ int ccm_search_by_projection(ccm_ctx* c, const ccm_frame_grid* f, const float* s
 int ccm_search_by_projection_frame(ccm_ctx* c, const ccm_frame_grid* f, const float* cur_angle, const float* scale_factors, int n_last,
                                    const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave, const float* last_angle,
                                    const uint8_t* mp_desc, const uint8_t* mp_has_obs, uint8_t* occupied, float th, int check_ori,
-                                   int32_t* match)
+                                   int orb_dist, int32_t* match)
 {
     if (!c || !f) return CCM_E_ARG;
     if (f->n < 0 || n_last < 0 || (f->n > 0 && (!match || !occupied || (check_ori && !cur_angle))) ||
@@ -403,7 +426,7 @@ int ccm_search_by_projection_frame(ccm_ctx* c, const ccm_frame_grid* f, const fl
             const int dist = cd[(size_t)i * cap + k];
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }
-        if (bestDist <= 100) {                                                 // TH_HIGH
+        if (bestDist <= orb_dist) {                                            // TH_HIGH (:1432) / ORBdist (:1556)
             match[bestIdx2] = i;
             occupied[bestIdx2] = mp_has_obs[i];
             nmatches++;
@@ -500,7 +523,7 @@ int ccm_search_for_initialization(ccm_ctx* c, int n1, const int32_t* oct1, const
 // Selection loop of ORBmatcher::Fuse, both overloads (ORBmatcher.cpp:914-955 and :1072-1100)
 int ccm_fuse_select(ccm_ctx* c, const ccm_frame_grid* kf, const float* scale_factors, const float* inv_level_sigma2, int n_mp,
                     const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, float th,
-                    int chi2_check, int32_t* best_idx, int32_t* best_dist)
+                    int chi2_check, int accept_th, int32_t* best_idx, int32_t* best_dist)
 {
     if (!c || !kf) return CCM_E_ARG;
     if (n_mp < 0 || kf->n < 0 || (n_mp > 0 && (!valid || !u || !v || !level || !mp_desc || !best_idx || !best_dist || !scale_factors)) ||
@@ -538,9 +561,149 @@ int ccm_fuse_select(ccm_ctx* c, const ccm_frame_grid* kf, const float* scale_fac
             if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
         }
         best_dist[m] = bestDist;
-        if (bestDist <= 50) best_idx[m] = bestIdx;                              // TH_LOW
+        if (bestDist <= accept_th) best_idx[m] = bestIdx;                       // TH_LOW (Fuse) / TH_HIGH (SearchBySim3)
     }
     return CCM_OK;
+}
+
+// ORBmatcher::SearchBySim3, ORBmatcher.cpp:1124-1348: two selection passes (<= TH_HIGH) and the agreement check
+int ccm_search_by_sim3(ccm_ctx* c, const ccm_frame_grid* kf1, const float* scale_factors1, const ccm_frame_grid* kf2, const float* scale_factors2,
+                       const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* mp_desc1,
+                       const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* mp_desc2,
+                       float th, int32_t* match12)
+{
+    if (!c || !kf1 || !kf2) return CCM_E_ARG;
+    if (kf1->n < 0 || kf2->n < 0 || (kf1->n > 0 && !match12)) return ccm_fail(c, CCM_E_ARG, "bad SearchBySim3 arguments");
+    const int n1 = kf1->n, n2 = kf2->n;
+    std::vector<int32_t> m1(std::max(n1, 1)), d1(std::max(n1, 1)), m2(std::max(n2, 1)), d2(std::max(n2, 1));
+    // map points of KF1 (one per feature of KF1) are searched in KF2, and vice versa
+    int rc = ccm_fuse_select(c, kf2, scale_factors2, nullptr, n1, valid1, u1, v1, level1, mp_desc1, th, 0, 100, m1.data(), d1.data());
+    if (rc) return rc;
+    rc = ccm_fuse_select(c, kf1, scale_factors1, nullptr, n2, valid2, u2, v2, level2, mp_desc2, th, 0, 100, m2.data(), d2.data());
+    if (rc) return rc;
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { match12[i1] = idx2; nFound++; }     // :1330-1345
+    }
+    return nFound;
+}
+
+// ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), ORBmatcher.cpp:308-446
+int ccm_search_by_projection_sim3(ccm_ctx* c, const ccm_frame_grid* kf, const float* scale_factors, int n_mp, const uint8_t* valid,
+                                  const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, const uint8_t* observed,
+                                  uint8_t* matched, float th, int32_t* best_idx)
+{
+    if (!c || !kf) return CCM_E_ARG;
+    if (n_mp < 0 || kf->n < 0 || (n_mp > 0 && (!valid || !u || !v || !level || !mp_desc || !observed || !best_idx || !scale_factors)) ||
+        (kf->n > 0 && !matched))
+        return ccm_fail(c, CCM_E_ARG, "bad SearchByProjection(kf, Scw) arguments");
+    for (int m = 0; m < n_mp; m++) best_idx[m] = -1;
+    if (n_mp == 0 || kf->n == 0) return 0;
+    CCM_HIP(c, hipSetDevice(c->device));
+    std::vector<float> qr(n_mp); std::vector<int32_t> none(n_mp, -1);
+    for (int m = 0; m < n_mp; m++) qr[m] = valid[m] ? th * scale_factors[level[m]] : -1.f;       // :380
+    int cap = 64;
+    std::vector<int32_t> ci, cd, cn;
+    for (;;) {
+        int rc = window_candidates(c, kf, n_mp, u, v, qr.data(), none.data(), none.data(), mp_desc, cap, ci, cd, cn);
+        if (rc) return rc;
+        int mx = 0;
+        for (int k : cn) mx = std::max(mx, k);
+        if (mx <= cap) break;
+        cap = mx;
+    }
+    int nmatches = 0;
+    for (int m = 0; m < n_mp; m++) {                       // sequential: vpMatched grows while the points are visited
+        if (!valid[m]) continue;
+        const int lvl = level[m];
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < cn[m]; k++) {
+            const int idx = ci[(size_t)m * cap + k];
+            if (matched[idx]) continue;                                                          // :394
+            const int kpLevel = kf->kp_octave[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            const int dist = cd[(size_t)m * cap + k];
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= 50) {                                                                    // TH_LOW
+            best_idx[m] = bestIdx;
+            if (!observed[m]) { matched[bestIdx] = 1; nmatches++; }                              // :436-440
+        }
+    }
+    return nmatches;
+}
+
+// ORBmatcher::CheckDistEpipolarLine, ORBmatcher.cpp:159-176
+static bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float* F12, float sigma2)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float cc = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + cc;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
+// ORBmatcher::SearchForTriangulation, ORBmatcher.cpp:700-852
+int ccm_search_for_triangulation(ccm_ctx* c, const uint8_t* desc1, const int32_t* node1, const uint8_t* has_mp1, const float* x1, const float* y1,
+                                 const float* angle1, int n1, const uint8_t* desc2, const int32_t* node2, const uint8_t* has_mp2,
+                                 const float* x2, const float* y2, const float* angle2, const int32_t* octave2, int n2, const float* F12,
+                                 float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int check_ori, int32_t* match12)
+{
+    if (!c) return CCM_E_ARG;
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && (!desc1 || !node1 || !has_mp1 || !x1 || !y1 || !match12 || (check_ori && !angle1))) ||
+        (n2 > 0 && (!desc2 || !node2 || !has_mp2 || !x2 || !y2 || !octave2 || (check_ori && !angle2))) || !F12 || !scale_factors2 || !level_sigma2_2)
+        return ccm_fail(c, CCM_E_ARG, "bad SearchForTriangulation arguments");
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    CCM_HIP(c, hipSetDevice(c->device));
+    std::vector<uint8_t> free1(n1);
+    for (int i = 0; i < n1; i++) free1[i] = !has_mp1[i];                                         // :744-746
+    BowRanges R;
+    int rc = bow_ranges(c, desc1, node1, free1.data(), n1, desc2, node2, n2, R);
+    if (rc) return rc;
+    const int HISTO = 30;
+    std::vector<int> rot[HISTO];
+    const float factor = 1.0f / HISTO;
+    int nmatches = 0;
+    for (int i1 : R.ord1) {
+        if (node1[i1] < 0 || !free1[i1] || R.len[i1] == 0) continue;
+        int bestDist = 50, bestIdx2 = -1;                                                       // TH_LOW
+        const unsigned short* d = R.dist.data() + R.off[i1];
+        for (int k = 0; k < R.len[i1]; k++) {
+            const int idx2 = R.ord2[R.start[i1] + k];
+            if (has_mp2[idx2]) continue;                                                         // :763; vbMatched2 is never set
+            const int dist = d[k];
+            if (dist > 50 || dist > bestDist) continue;
+            const float distex = ex - x2[idx2], distey = ey - y2[idx2];
+            if (distex * distex + distey * distey < 100 * scale_factors2[octave2[idx2]]) continue;
+            if (check_dist_epipolar_line(x1[i1], y1[i1], x2[idx2], y2[idx2], F12, level_sigma2_2[octave2[idx2]])) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+            match12[i1] = bestIdx2;
+            nmatches++;
+            if (check_ori) {
+                float r = angle1[i1] - angle2[bestIdx2];
+                if (r < 0.0) r += 360.0f;
+                int bin = (int)std::round(r * factor);
+                if (bin == HISTO) bin = 0;
+                rot[bin].push_back(i1);
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(rot, HISTO, i1, i2, i3);
+        for (int i = 0; i < HISTO; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx : rot[i]) { match12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
 }
 
 }  // extern "C"

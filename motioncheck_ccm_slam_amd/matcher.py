@@ -129,8 +129,9 @@ ORBmatcher.SearchByProjection = _search_by_projection
 
 
 def _search_by_projection_frame(self, cur: FrameGridView, cur_angle, scale_factors, valid, u, v, last_octave, last_angle, mp_desc,
-                                mp_has_obs, occupied, th: float):
-    """ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th) (ORBmatcher.cpp:1350-1476)."""
+                                mp_has_obs, occupied, th: float, orb_dist: int = 100):
+    """ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th) (ORBmatcher.cpp:1350-1476); with
+    mp_has_obs all ones and orb_dist = ORBdist also SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1478-1605)."""
     a = np.ascontiguousarray
     ca = a(cur_angle, "f4"); sf = a(scale_factors, "f4"); va = a(valid, np.uint8); uu = a(u, "f4"); vv = a(v, "f4")
     lo = a(last_octave, "i4"); la = a(last_angle, "f4"); md = a(mp_desc, np.uint8); ho = a(mp_has_obs, np.uint8)
@@ -139,7 +140,7 @@ def _search_by_projection_frame(self, cur: FrameGridView, cur_angle, scale_facto
     g = cur.struct()
     p = _lib.ptr
     n = self.ctx.check(self.lib.ccm_search_by_projection_frame(self.ctx.handle, C.byref(g), p(ca), p(sf), len(va), p(va), p(uu), p(vv), p(lo),
-                                                               p(la), p(md), p(ho), p(occ), C.c_float(th), int(self.mbCheckOrientation), p(match)))
+                                                               p(la), p(md), p(ho), p(occ), C.c_float(th), int(self.mbCheckOrientation), int(orb_dist), p(match)))
     return n, match[:len(cur.kx)], occ
 
 
@@ -162,7 +163,8 @@ def _search_for_initialization(self, oct1, desc1, angle1, f2: FrameGridView, ang
 ORBmatcher.SearchForInitialization = _search_for_initialization
 
 
-def _fuse_select(self, kf: FrameGridView, scale_factors, inv_level_sigma2, valid, u, v, level, mp_desc, th: float, chi2_check: bool):
+def _fuse_select(self, kf: FrameGridView, scale_factors, inv_level_sigma2, valid, u, v, level, mp_desc, th: float, chi2_check: bool,
+                 accept_th: int = 50):
     """Selection loop of ORBmatcher::Fuse (both overloads).  Returns (best_idx, best_dist) per map point."""
     a = np.ascontiguousarray
     sf = a(scale_factors, "f4"); s2 = a(inv_level_sigma2, "f4"); va = a(valid, np.uint8); uu = a(u, "f4"); vv = a(v, "f4")
@@ -172,8 +174,56 @@ def _fuse_select(self, kf: FrameGridView, scale_factors, inv_level_sigma2, valid
     g = kf.struct()
     p = _lib.ptr
     self.ctx.check(self.lib.ccm_fuse_select(self.ctx.handle, C.byref(g), p(sf), p(s2), n, p(va), p(uu), p(vv), p(lv), p(md), C.c_float(th),
-                                            int(chi2_check), p(bi), p(bd)))
+                                            int(chi2_check), int(accept_th), p(bi), p(bd)))
     return bi[:n], bd[:n]
 
 
 ORBmatcher.FuseSelect = _fuse_select
+
+
+def _search_by_sim3(self, kf1: FrameGridView, sf1, kf2: FrameGridView, sf2, valid1, u1, v1, level1, mp_desc1, valid2, u2, v2, level2, mp_desc2,
+                    th: float):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cpp:1124-1348) after the caller's projections.  Returns (nFound, match12)."""
+    a = np.ascontiguousarray
+    arrs = [a(sf1, "f4"), a(sf2, "f4"), a(valid1, np.uint8), a(u1, "f4"), a(v1, "f4"), a(level1, "i4"), a(mp_desc1, np.uint8),
+            a(valid2, np.uint8), a(u2, "f4"), a(v2, "f4"), a(level2, "i4"), a(mp_desc2, np.uint8)]
+    m12 = np.full(max(len(kf1.kx), 1), -1, "i4")
+    g1, g2 = kf1.struct(), kf2.struct()
+    p = _lib.ptr
+    n = self.ctx.check(self.lib.ccm_search_by_sim3(self.ctx.handle, C.byref(g1), p(arrs[0]), C.byref(g2), p(arrs[1]), *[p(x) for x in arrs[2:]],
+                                                   C.c_float(th), p(m12)))
+    return n, m12[:len(kf1.kx)]
+
+
+def _search_by_projection_sim3(self, kf: FrameGridView, scale_factors, valid, u, v, level, mp_desc, observed, matched, th: float):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cpp:308-446).
+    Returns (nmatches, best_idx per map point, matched after the call)."""
+    a = np.ascontiguousarray
+    sf = a(scale_factors, "f4"); va = a(valid, np.uint8); uu = a(u, "f4"); vv = a(v, "f4"); lv = a(level, "i4"); md = a(mp_desc, np.uint8)
+    ob = a(observed, np.uint8); mt = a(matched, np.uint8).copy()
+    bi = np.full(max(len(va), 1), -1, "i4")
+    g = kf.struct()
+    p = _lib.ptr
+    n = self.ctx.check(self.lib.ccm_search_by_projection_sim3(self.ctx.handle, C.byref(g), p(sf), len(va), p(va), p(uu), p(vv), p(lv), p(md), p(ob),
+                                                              p(mt), C.c_float(th), p(bi)))
+    return n, bi[:len(va)], mt
+
+
+def _search_for_triangulation(self, desc1, node1, has_mp1, x1, y1, angle1, desc2, node2, has_mp2, x2, y2, angle2, octave2, F12, ex, ey,
+                              scale_factors2, level_sigma2_2):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cpp:700-852).  Returns (nmatches, match12)."""
+    a = np.ascontiguousarray
+    d1 = a(desc1, np.uint8); n1 = a(node1, "i4"); h1 = a(has_mp1, np.uint8); xx1 = a(x1, "f4"); yy1 = a(y1, "f4"); a1 = a(angle1, "f4")
+    d2 = a(desc2, np.uint8); n2 = a(node2, "i4"); h2 = a(has_mp2, np.uint8); xx2 = a(x2, "f4"); yy2 = a(y2, "f4"); a2 = a(angle2, "f4")
+    o2 = a(octave2, "i4"); F = a(F12, "f4").reshape(9); sf = a(scale_factors2, "f4"); s2 = a(level_sigma2_2, "f4")
+    m12 = np.full(max(len(d1), 1), -1, "i4")
+    p = _lib.ptr
+    n = self.ctx.check(self.lib.ccm_search_for_triangulation(self.ctx.handle, p(d1), p(n1), p(h1), p(xx1), p(yy1), p(a1), len(d1), p(d2), p(n2),
+                                                             p(h2), p(xx2), p(yy2), p(a2), p(o2), len(d2), p(F), C.c_float(ex), C.c_float(ey),
+                                                             p(sf), p(s2), int(self.mbCheckOrientation), p(m12)))
+    return n, m12[:len(d1)]
+
+
+ORBmatcher.SearchBySim3 = _search_by_sim3
+ORBmatcher.SearchByProjectionSim3 = _search_by_projection_sim3
+ORBmatcher.SearchForTriangulation = _search_for_triangulation

@@ -241,7 +241,7 @@ int orc_search_by_projection_frame(int n, const float* kx, const float* ky, cons
                                    float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
                                    int n_last, const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave,
                                    const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
-                                   uint8_t* occupied, float th, int check_ori, int32_t* match)
+                                   uint8_t* occupied, float th, int check_ori, int orb_dist, int32_t* match)
 {
     enum { HISTO = 30 };
     orc_grid* g = grid_build(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows);
@@ -264,7 +264,7 @@ int orc_search_by_projection_frame(int n, const float* kx, const float* ky, cons
             const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)i, desc + 32 * (size_t)i2);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }
-        if (bestDist <= 100) {
+        if (bestDist <= orb_dist) {                        /* TH_HIGH (:1432) or the ORBdist argument (:1556) */
             match[bestIdx2] = i;
             occupied[bestIdx2] = mp_has_obs[i];
             nmatches++;
@@ -357,7 +357,7 @@ int orc_search_for_initialization(int n1, const int32_t* oct1, const uint8_t* de
 void orc_fuse_select(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
                      float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
                      const float* inv_level_sigma2, int n_mp, const uint8_t* valid, const float* u, const float* v,
-                     const int32_t* level, const uint8_t* mp_desc, float th, int chi2_check, int32_t* best_idx, int32_t* best_dist)
+                     const int32_t* level, const uint8_t* mp_desc, float th, int chi2_check, int accept_th, int32_t* best_idx, int32_t* best_dist)
 {
     orc_grid* g = grid_build(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows);
     int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
@@ -381,7 +381,154 @@ void orc_fuse_select(int n, const float* kx, const float* ky, const int32_t* oct
             if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
         }
         best_dist[m] = bestDist;
-        if (bestDist <= 50) best_idx[m] = bestIdx;
+        if (bestDist <= accept_th) best_idx[m] = bestIdx;   /* TH_LOW in Fuse, TH_HIGH in SearchBySim3 (:1226, :1306) */
     }
     free(cand); grid_free(g);
+}
+
+/* ORBmatcher::SearchBySim3 (ORBmatcher.cpp:1124-1348) after the caller's projections: both directions pick the most
+ * similar feature (<= TH_HIGH), a pair is kept when the two directions agree (:1330-1345).  match12[i1] = i2 or -1. */
+int orc_search_by_sim3(int n1, const float* kx1, const float* ky1, const int32_t* oct1, const uint8_t* desc1, const float* grid1, const float* sf1,
+                       int n2, const float* kx2, const float* ky2, const int32_t* oct2, const uint8_t* desc2, const float* grid2, const float* sf2,
+                       int cols, int rows,
+                       const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* mpdesc1,
+                       const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* mpdesc2,
+                       float th, int32_t* match12)
+{
+    int32_t* m1 = (int32_t*)malloc(sizeof(int32_t) * (n1 > 0 ? n1 : 1)), *d1 = (int32_t*)malloc(sizeof(int32_t) * (n1 > 0 ? n1 : 1));
+    int32_t* m2 = (int32_t*)malloc(sizeof(int32_t) * (n2 > 0 ? n2 : 1)), *d2 = (int32_t*)malloc(sizeof(int32_t) * (n2 > 0 ? n2 : 1));
+    /* map points of KF1 are searched in KF2 and vice versa */
+    orc_fuse_select(n2, kx2, ky2, oct2, desc2, grid2[0], grid2[1], grid2[2], grid2[3], cols, rows, sf2, 0, n1, valid1, u1, v1, level1, mpdesc1, th, 0, 100, m1, d1);
+    orc_fuse_select(n1, kx1, ky1, oct1, desc1, grid1[0], grid1[1], grid1[2], grid1[3], cols, rows, sf1, 0, n2, valid2, u2, v2, level2, mpdesc2, th, 0, 100, m2, d2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+    }
+    free(m1); free(d1); free(m2); free(d2);
+    return nFound;
+}
+
+/* ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cpp:308-446) after the caller's
+ * projection (valid, u, v, predicted level).  matched (in/out) = vpMatched[idx] != null; observed[m] = the map point is
+ * already an observation of pKF (GetIndexInKeyFrame != -1: it is re-mapped by the caller, vpMatched is not touched, :414-434).
+ * best_idx[m] = chosen feature or -1.  Returns nmatches. */
+int orc_search_by_projection_sim3(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
+                                  float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                                  int n_mp, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc,
+                                  const uint8_t* observed, uint8_t* matched, float th, int32_t* best_idx)
+{
+    orc_grid* g = grid_build(n, kx, ky, min_x, min_y, inv_w, inv_h, cols, rows);
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    int nmatches = 0;
+    for (int m = 0; m < n_mp; m++) {
+        best_idx[m] = -1;
+        if (!valid[m]) continue;
+        const int lvl = level[m];
+        const float radius = th * scale_factors[lvl];
+        const int nc = features_in_area(g, kx, ky, oct, u[m], v[m], radius, -1, -1, cand, n);
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = cand[k];
+            if (matched[idx]) continue;
+            if (oct[idx] < lvl - 1 || oct[idx] > lvl) continue;
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)m, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= 50) {
+            best_idx[m] = bestIdx;
+            if (!observed[m]) { matched[bestIdx] = 1; nmatches++; }
+        }
+    }
+    free(cand); grid_free(g);
+    return nmatches;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine (ORBmatcher.cpp:159-176); F12 row-major 3x3 float */
+static int check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float* F12, float sigma2)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cpp:700-852).  has_mp = the feature already has a map point;
+ * (ex, ey) = the epipole in image 2 (:707-714, computed by the caller).  This version never sets vbMatched2, so
+ * several features of image 1 may choose the same feature of image 2.  match12[i1] = i2 or -1. */
+int orc_search_for_triangulation(const uint8_t* desc1, const int32_t* node1, const uint8_t* has_mp1, const float* x1, const float* y1,
+                                 const float* angle1, int n1,
+                                 const uint8_t* desc2, const int32_t* node2, const uint8_t* has_mp2, const float* x2, const float* y2,
+                                 const float* angle2, const int32_t* oct2, int n2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                 int check_ori, int32_t* match12)
+{
+    enum { HISTO = 30 };
+    nf* f1 = (nf*)malloc(sizeof(nf) * (n1 > 0 ? n1 : 1));
+    nf* f2 = (nf*)malloc(sizeof(nf) * (n2 > 0 ? n2 : 1));
+    int32_t* hist = (int32_t*)malloc(sizeof(int32_t) * HISTO * (size_t)(n1 > 0 ? n1 : 1));
+    int32_t hn[HISTO];
+    memset(hn, 0, sizeof hn);
+    int m1 = 0, m2 = 0;
+    for (int i = 0; i < n1; i++) { match12[i] = -1; if (node1[i] >= 0) { f1[m1].node = node1[i]; f1[m1].idx = i; m1++; } }
+    for (int i = 0; i < n2; i++) if (node2[i] >= 0) { f2[m2].node = node2[i]; f2[m2].idx = i; m2++; }
+    qsort(f1, m1, sizeof(nf), nf_cmp);
+    qsort(f2, m2, sizeof(nf), nf_cmp);
+    const float factor = 1.0f / HISTO;
+    int nmatches = 0;
+    int a = 0, b = 0;
+    while (a < m1 && b < m2) {
+        if (f1[a].node == f2[b].node) {
+            int ae = a, be = b;
+            while (ae < m1 && f1[ae].node == f1[a].node) ae++;
+            while (be < m2 && f2[be].node == f2[b].node) be++;
+            for (int i = a; i < ae; i++) {
+                const int idx1 = f1[i].idx;
+                if (has_mp1[idx1]) continue;                                           /* :744-746 */
+                int bestDist = 50, bestIdx2 = -1;                                      /* TH_LOW */
+                for (int j = b; j < be; j++) {
+                    const int idx2 = f2[j].idx;
+                    if (has_mp2[idx2]) continue;                                       /* :763 (vbMatched2 stays false) */
+                    const int dist = orc_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist > 50 || dist > bestDist) continue;                        /* :770 */
+                    const float distex = ex - x2[idx2], distey = ey - y2[idx2];
+                    if (distex * distex + distey * distey < 100 * scale_factors2[oct2[idx2]]) continue;   /* :775-777 */
+                    if (check_dist_epipolar_line(x1[idx1], y1[idx1], x2[idx2], y2[idx2], F12, level_sigma2_2[oct2[idx2]])) {
+                        bestIdx2 = idx2; bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_ori) {
+                        float rot = angle1[idx1] - angle2[bestIdx2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO) bin = 0;
+                        hist[bin * (size_t)n1 + hn[bin]++] = idx1;
+                    }
+                }
+            }
+            a = ae; b = be;
+        } else if (f1[a].node < f2[b].node) {
+            while (a < m1 && f1[a].node < f2[b].node) a++;
+        } else {
+            while (b < m2 && f2[b].node < f1[a].node) b++;
+        }
+    }
+    if (check_ori) {
+        int32_t ind[3];
+        orc_three_maxima(hn, HISTO, ind);
+        for (int i = 0; i < HISTO; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (int j = 0; j < hn[i]; j++) { match12[hist[i * (size_t)n1 + j]] = -1; nmatches--; }
+        }
+    }
+    free(f1); free(f2); free(hist);
+    return nmatches;
 }

@@ -73,7 +73,7 @@ int  orc_search_by_projection_frame(int n, const float* kx, const float* ky, con
                                     float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
                                     int n_last, const uint8_t* valid, const float* u, const float* v, const int32_t* last_octave,
                                     const float* last_angle, const uint8_t* mp_desc, const uint8_t* mp_has_obs,
-                                    uint8_t* occupied, float th, int check_ori, int32_t* match);
+                                    uint8_t* occupied, float th, int check_ori, int orb_dist, int32_t* match);
 
 int  orc_search_for_initialization(int n1, const int32_t* oct1, const uint8_t* desc1, const float* angle1,
                                    int n2, const float* kx2, const float* ky2, const int32_t* oct2, const uint8_t* desc2, const float* angle2,
@@ -83,7 +83,24 @@ int  orc_search_for_initialization(int n1, const int32_t* oct1, const uint8_t* d
 void orc_fuse_select(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
                      float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
                      const float* inv_level_sigma2, int n_mp, const uint8_t* valid, const float* u, const float* v,
-                     const int32_t* level, const uint8_t* mp_desc, float th, int chi2_check, int32_t* best_idx, int32_t* best_dist);
+                     const int32_t* level, const uint8_t* mp_desc, float th, int chi2_check, int accept_th, int32_t* best_idx, int32_t* best_dist);
+
+int orc_search_by_sim3(int n1, const float* kx1, const float* ky1, const int32_t* oct1, const uint8_t* desc1, const float* grid1, const float* sf1,
+                       int n2, const float* kx2, const float* ky2, const int32_t* oct2, const uint8_t* desc2, const float* grid2, const float* sf2,
+                       int cols, int rows,
+                       const uint8_t* valid1, const float* u1, const float* v1, const int32_t* level1, const uint8_t* mpdesc1,
+                       const uint8_t* valid2, const float* u2, const float* v2, const int32_t* level2, const uint8_t* mpdesc2,
+                       float th, int32_t* match12);
+int orc_search_by_projection_sim3(int n, const float* kx, const float* ky, const int32_t* oct, const uint8_t* desc,
+                                  float min_x, float min_y, float inv_w, float inv_h, int cols, int rows, const float* scale_factors,
+                                  int n_mp, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc,
+                                  const uint8_t* observed, uint8_t* matched, float th, int32_t* best_idx);
+int orc_search_for_triangulation(const uint8_t* desc1, const int32_t* node1, const uint8_t* has_mp1, const float* x1, const float* y1,
+                                 const float* angle1, int n1,
+                                 const uint8_t* desc2, const int32_t* node2, const uint8_t* has_mp2, const float* x2, const float* y2,
+                                 const float* angle2, const int32_t* oct2, int n2,
+                                 const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                 int check_ori, int32_t* match12);
 
 /* ---- bundle adjustment ---- */
 typedef struct {

@@ -232,7 +232,7 @@ def search_by_projection(kx, ky, octv, desc, min_x, min_y, inv_w, inv_h, scale_f
 
 
 def search_by_projection_frame(kx, ky, octv, desc, angle, min_x, min_y, inv_w, inv_h, scale_factors, valid, u, v, last_octave, last_angle,
-                               mp_desc, mp_has_obs, occupied, th, check_ori, cols=75, rows=48):
+                               mp_desc, mp_has_obs, occupied, th, check_ori, cols=75, rows=48, orb_dist=100):
     a = lambda x, t: np.ascontiguousarray(x, t)
     kx = a(kx, "f4"); ky = a(ky, "f4"); octv = a(octv, "i4"); desc = a(desc, np.uint8); angle = a(angle, "f4"); sf = a(scale_factors, "f4")
     va = a(valid, np.uint8); u = a(u, "f4"); v = a(v, "f4"); lo = a(last_octave, "i4"); la = a(last_angle, "f4")
@@ -240,7 +240,7 @@ def search_by_projection_frame(kx, ky, octv, desc, angle, min_x, min_y, inv_w, i
     match = np.full(max(len(kx), 1), -1, "i4")
     n = lib().orc_search_by_projection_frame(len(kx), _p(kx), _p(ky), _p(octv), _p(desc), _p(angle), C.c_float(min_x), C.c_float(min_y),
                                              C.c_float(inv_w), C.c_float(inv_h), cols, rows, _p(sf), len(va), _p(va), _p(u), _p(v), _p(lo),
-                                             _p(la), _p(md), _p(ho), _p(occ), C.c_float(th), int(check_ori), _p(match))
+                                             _p(la), _p(md), _p(ho), _p(occ), C.c_float(th), int(check_ori), int(orb_dist), _p(match))
     return n, match[:len(kx)].copy(), occ
 
 
@@ -257,11 +257,48 @@ def search_for_initialization(oct1, desc1, angle1, kx2, ky2, oct2, desc2, angle2
 
 
 def fuse_select(kx, ky, octv, desc, min_x, min_y, inv_w, inv_h, scale_factors, inv_level_sigma2, valid, u, v, level, mp_desc, th, chi2_check,
-                cols=75, rows=48):
+                cols=75, rows=48, accept_th=50):
     a = lambda x, t: np.ascontiguousarray(x, t)
     kx = a(kx, "f4"); ky = a(ky, "f4"); octv = a(octv, "i4"); desc = a(desc, np.uint8); sf = a(scale_factors, "f4"); s2 = a(inv_level_sigma2, "f4")
     va = a(valid, np.uint8); u = a(u, "f4"); v = a(v, "f4"); lv = a(level, "i4"); md = a(mp_desc, np.uint8)
     n = len(va); bi = np.full(max(n, 1), -1, "i4"); bd = np.full(max(n, 1), 256, "i4")
     lib().orc_fuse_select(len(kx), _p(kx), _p(ky), _p(octv), _p(desc), C.c_float(min_x), C.c_float(min_y), C.c_float(inv_w), C.c_float(inv_h),
-                          cols, rows, _p(sf), _p(s2), n, _p(va), _p(u), _p(v), _p(lv), _p(md), C.c_float(th), int(chi2_check), _p(bi), _p(bd))
+                          cols, rows, _p(sf), _p(s2), n, _p(va), _p(u), _p(v), _p(lv), _p(md), C.c_float(th), int(chi2_check), int(accept_th), _p(bi), _p(bd))
     return bi[:n].copy(), bd[:n].copy()
+
+
+def search_by_sim3(f1, sf1, f2, sf2, valid1, u1, v1, level1, mpdesc1, valid2, u2, v2, level2, mpdesc2, th, cols=75, rows=48):
+    """f1, f2: objects with kx, ky, oct, desc, min_x, min_y, inv_w, inv_h (matcher.FrameGridView)."""
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    g1 = np.array([f1.min_x, f1.min_y, f1.inv_w, f1.inv_h], "f4"); g2 = np.array([f2.min_x, f2.min_y, f2.inv_w, f2.inv_h], "f4")
+    sf1 = a(sf1, "f4"); sf2 = a(sf2, "f4")
+    A = [a(valid1, np.uint8), a(u1, "f4"), a(v1, "f4"), a(level1, "i4"), a(mpdesc1, np.uint8),
+         a(valid2, np.uint8), a(u2, "f4"), a(v2, "f4"), a(level2, "i4"), a(mpdesc2, np.uint8)]
+    m12 = np.full(max(len(f1.kx), 1), -1, "i4")
+    n = lib().orc_search_by_sim3(len(f1.kx), _p(f1.kx), _p(f1.ky), _p(f1.oct), _p(f1.desc), _p(g1), _p(sf1),
+                                 len(f2.kx), _p(f2.kx), _p(f2.ky), _p(f2.oct), _p(f2.desc), _p(g2), _p(sf2), cols, rows,
+                                 *[_p(x) for x in A], C.c_float(th), _p(m12))
+    return n, m12[:len(f1.kx)].copy()
+
+
+def search_by_projection_sim3(f, scale_factors, valid, u, v, level, mp_desc, observed, matched, th, cols=75, rows=48):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    sf = a(scale_factors, "f4"); va = a(valid, np.uint8); u = a(u, "f4"); v = a(v, "f4"); lv = a(level, "i4"); md = a(mp_desc, np.uint8)
+    ob = a(observed, np.uint8); mt = a(matched, np.uint8).copy()
+    bi = np.full(max(len(va), 1), -1, "i4")
+    n = lib().orc_search_by_projection_sim3(len(f.kx), _p(f.kx), _p(f.ky), _p(f.oct), _p(f.desc), C.c_float(f.min_x), C.c_float(f.min_y),
+                                            C.c_float(f.inv_w), C.c_float(f.inv_h), cols, rows, _p(sf), len(va), _p(va), _p(u), _p(v), _p(lv),
+                                            _p(md), _p(ob), _p(mt), C.c_float(th), _p(bi))
+    return n, bi[:len(va)].copy(), mt
+
+
+def search_for_triangulation(desc1, node1, has_mp1, x1, y1, angle1, desc2, node2, has_mp2, x2, y2, angle2, octave2, F12, ex, ey,
+                             scale_factors2, level_sigma2_2, check_ori):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    d1 = a(desc1, np.uint8); n1 = a(node1, "i4"); h1 = a(has_mp1, np.uint8); xx1 = a(x1, "f4"); yy1 = a(y1, "f4"); a1 = a(angle1, "f4")
+    d2 = a(desc2, np.uint8); n2 = a(node2, "i4"); h2 = a(has_mp2, np.uint8); xx2 = a(x2, "f4"); yy2 = a(y2, "f4"); a2 = a(angle2, "f4")
+    o2 = a(octave2, "i4"); F = a(F12, "f4").reshape(9); sf = a(scale_factors2, "f4"); s2 = a(level_sigma2_2, "f4")
+    m12 = np.full(max(len(d1), 1), -1, "i4")
+    n = lib().orc_search_for_triangulation(_p(d1), _p(n1), _p(h1), _p(xx1), _p(yy1), _p(a1), len(d1), _p(d2), _p(n2), _p(h2), _p(xx2), _p(yy2),
+                                           _p(a2), _p(o2), len(d2), _p(F), C.c_float(ex), C.c_float(ey), _p(sf), _p(s2), int(check_ori), _p(m12))
+    return n, m12[:len(d1)].copy()

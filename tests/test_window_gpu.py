@@ -129,3 +129,109 @@ def test_fuse_select(ctx, oracle, chi2):
         rbi, rbd = oracle.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, valid, u, v, level, mp_desc, th, chi2)
         assert (bi == rbi).all() and (bd == rbd).all()
         assert (bi[:900] >= 0).sum() > 400 and (bi[~valid] == -1).all()
+
+
+def _noisy_points(fr, desc, rng, n_rel, n_rand, sigma=1.2, flip=0.04):
+    """Map points = features of frame `fr` re-projected with noise (+ unrelated ones): desc, u, v, level."""
+    n = len(fr.kx)
+    src = rng.integers(0, n, n_rel)
+    flips = np.packbits(rng.random((n_rel, 256)) < flip, axis=1, bitorder="little")
+    mp_desc = np.concatenate([desc[src] ^ flips, rng.integers(0, 256, (n_rand, 32), dtype=np.uint8)])
+    u = np.concatenate([fr.kx[src] + rng.normal(0, sigma, n_rel), rng.uniform(0, 752, n_rand)]).astype("f4")
+    v = np.concatenate([fr.ky[src] + rng.normal(0, sigma, n_rel), rng.uniform(0, 480, n_rand)]).astype("f4")
+    level = np.concatenate([np.clip(fr.oct[src] + rng.integers(0, 2, n_rel), 0, 7), rng.integers(0, 8, n_rand)])
+    return mp_desc, u, v, level, src
+
+
+def test_search_by_sim3(ctx, oracle):
+    """Two keyframes = two extractions; the 'map points' of each are noisy copies of the OTHER keyframe's features so
+    that the two directions agree on many pairs and disagree on some."""
+    f1, sf, k1, d1 = _frame(ctx, 5)
+    f2, _, k2, d2 = _frame(ctx, 6)
+    rng = np.random.default_rng(11)
+    n1, n2 = len(f1.kx), len(f2.kx)
+    # feature i1 of KF1 carries a map point that projects near feature p12[i1] of KF2, and the reverse for KF2
+    p12 = rng.integers(0, n2, n1)
+    fl = np.packbits(rng.random((n1, 256)) < 0.05, axis=1, bitorder="little")
+    mp1 = d2[p12] ^ fl
+    u1 = (f2.kx[p12] + rng.normal(0, 1.0, n1)).astype("f4"); v1 = (f2.ky[p12] + rng.normal(0, 1.0, n1)).astype("f4")
+    l1 = np.clip(f2.oct[p12] + rng.integers(0, 2, n1), 0, 7)
+    p21 = rng.integers(0, n1, n2)
+    back = rng.random(n2) < 0.7                                   # 70 %: KF2's point is the partner chosen by KF1's feature
+    inv = np.full(n2, -1); inv[p12] = np.arange(n1)
+    p21 = np.where(back & (inv >= 0), inv, p21)
+    fl2 = np.packbits(rng.random((n2, 256)) < 0.05, axis=1, bitorder="little")
+    mp2 = d1[p21] ^ fl2
+    u2 = (f1.kx[p21] + rng.normal(0, 1.0, n2)).astype("f4"); v2 = (f1.ky[p21] + rng.normal(0, 1.0, n2)).astype("f4")
+    l2 = np.clip(f1.oct[p21] + rng.integers(0, 2, n2), 0, 7)
+    val1 = rng.random(n1) < 0.9; val2 = rng.random(n2) < 0.9
+    m = ORBmatcher(ctx=ctx)
+    for th in (7.5, 3.0):
+        n, m12 = m.SearchBySim3(f1, sf, f2, sf, val1, u1, v1, l1, mp1, val2, u2, v2, l2, mp2, th)
+        rn, r12 = oracle.search_by_sim3(f1, sf, f2, sf, val1, u1, v1, l1, mp1, val2, u2, v2, l2, mp2, th)
+        assert n == rn and (m12 == r12).all()
+        assert n > 100 and (m12 < 0).sum() > 100
+
+
+def test_search_by_projection_sim3(ctx, oracle):
+    fr, sf, kps, desc = _frame(ctx, 7)
+    rng = np.random.default_rng(12)
+    mp_desc, u, v, level, src = _noisy_points(fr, desc, rng, 1400, 200)      # several points compete for the same feature
+    valid = rng.random(1600) < 0.9
+    observed = rng.random(1600) < 0.15
+    matched = rng.random(len(fr.kx)) < 0.2
+    m = ORBmatcher(ctx=ctx)
+    for th in (10.0, 4.0):
+        n, bi, mt = m.SearchByProjectionSim3(fr, sf, valid, u, v, level, mp_desc, observed, matched, th)
+        rn, rbi, rmt = oracle.search_by_projection_sim3(fr, sf, valid, u, v, level, mp_desc, observed, matched, th)
+        assert n == rn and (bi == rbi).all() and (mt == rmt).all()
+        assert n > 200 and (mt.sum() - matched.sum()) == n
+
+
+def test_search_by_projection_keyframe_overload(ctx, oracle):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): has_obs all ones, ORBdist 64."""
+    fr, sf, kps, desc = _frame(ctx, 8)
+    rng = np.random.default_rng(13)
+    mp_desc, u, v, level, src = _noisy_points(fr, desc, rng, 800, 100, flip=0.12)
+    nmp = 900
+    valid = rng.random(nmp) < 0.9
+    kf_angle = rng.uniform(0, 360, nmp).astype("f4")
+    kf_angle[:800] = (kps["angle"][src] + rng.normal(0, 3, 800)) % 360
+    occ = rng.random(len(fr.kx)) < 0.3
+    ones = np.ones(nmp, np.uint8)
+    m = ORBmatcher(0.9, True, ctx=ctx)
+    for dist in (64, 100):
+        n, match, o2 = m.SearchByProjectionFrame(fr, kps["angle"], sf, valid, u, v, level, kf_angle, mp_desc, ones, occ, 10.0, orb_dist=dist)
+        rn, rmatch, ro2 = oracle.search_by_projection_frame(fr.kx, fr.ky, fr.oct, desc, kps["angle"], fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf,
+                                                            valid, u, v, level, kf_angle, mp_desc, ones, occ, 10.0, True, orb_dist=dist)
+        assert n == rn and (match == rmatch).all() and (o2 == ro2).all()
+    assert n > 100
+
+
+def test_search_for_triangulation(ctx, oracle):
+    f1, sf, k1, d1 = _frame(ctx, 9)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+    sig2 = ex.GetScaleSigmaSquares()
+    rng = np.random.default_rng(14)
+    n1 = len(f1.kx)
+    # image 2 = image 1 shifted by a pure x translation of the camera: the epipolar lines are the image rows
+    n2 = n1 + 150
+    perm = rng.permutation(n1)
+    disp = rng.uniform(2, 40, n1).astype("f4")
+    x2 = np.concatenate([f1.kx[perm] - disp, rng.uniform(0, 752, 150)]).astype("f4")
+    y2 = np.concatenate([f1.ky[perm] + rng.normal(0, 0.8, n1), rng.uniform(0, 480, 150)]).astype("f4")
+    fl = np.packbits(rng.random((n1, 256)) < 0.06, axis=1, bitorder="little")
+    d2 = np.concatenate([d1[perm] ^ fl, rng.integers(0, 256, (150, 32), dtype=np.uint8)])
+    a2 = np.concatenate([(k1["angle"][perm] + rng.normal(0, 4, n1)) % 360, rng.uniform(0, 360, 150)]).astype("f4")
+    o2 = np.concatenate([f1.oct[perm], rng.integers(0, 8, 150)])
+    node1 = rng.integers(0, 60, n1); node1[rng.random(n1) < 0.03] = -1
+    node2 = np.concatenate([np.where(rng.random(n1) < 0.9, node1[perm], rng.integers(0, 60, n1)), rng.integers(0, 60, 150)])
+    has1 = rng.random(n1) < 0.4; has2 = rng.random(n2) < 0.3
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], "f4") + rng.normal(0, 1e-4, (3, 3)).astype("f4")   # [t]x for t = (1,0,0), perturbed
+    ex_, ey_ = 300.0, 240.0                                        # an epipole inside the image: features near it are rejected
+    for ori in (True, False):
+        m = ORBmatcher(0.6, ori, ctx=ctx)
+        n, m12 = m.SearchForTriangulation(d1, node1, has1, f1.kx, f1.ky, k1["angle"], d2, node2, has2, x2, y2, a2, o2, F12, ex_, ey_, sf, sig2)
+        rn, r12 = oracle.search_for_triangulation(d1, node1, has1, f1.kx, f1.ky, k1["angle"], d2, node2, has2, x2, y2, a2, o2, F12, ex_, ey_, sf, sig2, ori)
+        assert n == rn and (m12 == r12).all()
+        assert n > 100 and (m12[has1] == -1).all()

@@ -256,6 +256,39 @@ int ccm_search_for_triangulation(ccm_ctx*, const uint8_t* desc1, const int32_t* 
                                  const float* x2, const float* y2, const float* angle2, const int32_t* octave2, int n2, const float* F12,
                                  float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int check_ori, int32_t* match12);
 
+/* ---------------------------------------------------------------- vocabulary tree
+ * DBoW2::TemplatedVocabulary (cslam/thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  A vocabulary is handed over as
+ * the arrays loadFromTextFile (:1338-1423) fills: node 0 = root, parent[i] < i, descriptors [n_nodes][32], weights
+ * [n_nodes]; children keep node-id order, a node without children is a word, words are numbered in node order.
+ * The tree lives on the context's device until ccm_voc_destroy. */
+typedef struct ccm_vocabulary ccm_vocabulary;
+int  ccm_voc_create(ccm_ctx*, int k, int L, int n_nodes, const int32_t* parent, const uint8_t* descriptors, const double* weights,
+                    ccm_vocabulary** out);
+void ccm_voc_destroy(ccm_vocabulary*);
+int  ccm_voc_words(const ccm_vocabulary*);
+
+/* transform(feature, word_id, weight, nid, levelsup) (:1217-1258) for n features: the L-level k-way Hamming descent.
+ * node_id = the node at level L - levelsup (0 = root when that is <= 0 or the branch ends above it).  The _dev form
+ * takes descriptors resident on the device (ccm_orb_result_dev); results are host arrays. */
+int ccm_voc_transform(ccm_vocabulary*, const uint8_t* features, int n, int levelsup, int32_t* word_id, double* weight, int32_t* node_id);
+int ccm_voc_transform_dev(ccm_vocabulary*, const uint8_t* features_dev, int n, int levelsup, int32_t* word_id, double* weight,
+                          int32_t* node_id);
+
+/* transform(features, BowVector&, FeatureVector&, levelsup) (:1125-1193) from the per-feature results: out_id/out_val
+ * (room for n entries) = the BowVector in key order after the weighting (0 TF_IDF, 1 TF, 2 IDF, 3 BINARY) and the
+ * normalisation the scoring type asks for (0 L1_NORM ... 5 DOT_PRODUCT, BowVector.h:36-53); fv_node[i] = FeatureVector
+ * node of feature i, -1 when its word is stopped -- the per-feature form ccm_match_bow takes.  Returns the size. */
+int ccm_bow_vector(int n, const int32_t* word_id, const double* weight, const int32_t* node_id, int weighting, int scoring,
+                   int32_t* out_id, double* out_val, int32_t* fv_node);
+/* L1Scoring::score (ScoringObject.cpp:23-68) of two BowVectors in key order */
+double ccm_bow_score_l1(int n1, const int32_t* id1, const double* v1, int n2, const int32_t* id2, const double* v2);
+
+/* MapPoint::ComputeDistinctiveDescriptors (cslam/src/MapPoint.cpp:929-994) for n_points map points: the observed
+ * descriptors of point p are desc[first[p] .. first[p]+count[p]); best[p] = index (within the point) of the descriptor
+ * with the least median distance to the others, first among equals; -1 for count 0. */
+int ccm_distinctive_descriptors(ccm_vocabulary*, const uint8_t* desc, const int64_t* first, const int32_t* count, int n_points,
+                                int32_t* best);
+
 /* ---------------------------------------------------------------- optimizer
  * The 6-DoF pose / 3-DoF point reprojection BA that Optimizer::BundleAdjustmentClient
  * (src/Optimizer.cpp:32-212), LocalBundleAdjustmentClient (:349-644) and

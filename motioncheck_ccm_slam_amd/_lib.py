@@ -29,7 +29,8 @@ SYMBOLS = [
     "ccm_orb_result_dev", "ccm_orb_debug_level", "ccm_orb_debug_candidates",
     "ccm_descriptor_distance", "ccm_hamming_match", "ccm_hamming_match_dev", "ccm_ratio_test", "ccm_match_bow",
     "ccm_window_candidates", "ccm_search_by_projection", "ccm_search_by_projection_frame", "ccm_search_for_initialization", "ccm_fuse_select", "ccm_search_by_sim3", "ccm_search_by_projection_sim3",
-    "ccm_search_for_triangulation",
+    "ccm_search_for_triangulation", "ccm_voc_create", "ccm_voc_destroy", "ccm_voc_words", "ccm_voc_transform", "ccm_voc_transform_dev",
+    "ccm_bow_vector", "ccm_bow_score_l1", "ccm_distinctive_descriptors",
     "ccm_ba_solve", "ccm_ba_landmark_cuts", "ccm_pose_optimize", "ccm_comm_unique_id", "ccm_comm_init", "ccm_comm_destroy",
     "ccm_pose_from_mat4f", "ccm_pose_to_mat4f",
 ]
@@ -131,6 +132,14 @@ def load():
     lib.ccm_search_by_sim3.argtypes = [vp, C.POINTER(FrameGrid), vp, C.POINTER(FrameGrid), vp] + [vp] * 10 + [C.c_float, vp]
     lib.ccm_search_by_projection_sim3.argtypes = [vp, C.POINTER(FrameGrid), vp, C.c_int] + [vp] * 7 + [C.c_float, vp]
     lib.ccm_search_for_triangulation.argtypes = [vp] * 7 + [C.c_int] + [vp] * 7 + [C.c_int, vp, C.c_float, C.c_float, vp, vp, C.c_int, vp]
+    lib.ccm_voc_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(vp)]
+    lib.ccm_voc_destroy.argtypes = [vp]; lib.ccm_voc_destroy.restype = None
+    lib.ccm_voc_words.argtypes = [vp]
+    lib.ccm_voc_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.ccm_voc_transform_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.ccm_bow_vector.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.ccm_bow_score_l1.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp]; lib.ccm_bow_score_l1.restype = C.c_double
+    lib.ccm_distinctive_descriptors.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     lib.ccm_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaResult)]
     lib.ccm_ba_landmark_cuts.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.ccm_pose_optimize.argtypes = [vp, C.POINTER(PoseProblem)]

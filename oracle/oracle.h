@@ -102,6 +102,16 @@ int orc_search_for_triangulation(const uint8_t* desc1, const int32_t* node1, con
                                  const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
                                  int check_ori, int32_t* match12);
 
+/* ---- vocabulary tree (bow_oracle.c) ---- */
+typedef struct orc_voc orc_voc;
+orc_voc* orc_voc_create(int k, int L, int n_nodes, const int32_t* parent, const uint8_t* desc, const double* weight);
+void orc_voc_destroy(orc_voc*);
+void orc_voc_transform(const orc_voc*, const uint8_t* features, int n, int levelsup, int32_t* word_id, double* weight, int32_t* node_id);
+int orc_bow_vector(int n, const int32_t* word_id, const double* weight, const int32_t* node_id, int weighting, int scoring,
+                   int32_t* out_id, double* out_val, int32_t* fv_node);
+double orc_bow_score_l1(int n1, const int32_t* id1, const double* v1, int n2, const int32_t* id2, const double* v2);
+int orc_distinctive_descriptor(const uint8_t* desc, int n);
+
 /* ---- bundle adjustment ---- */
 typedef struct {
     int n_poses; double* poses; const uint8_t* fixed; const double* intr;

@@ -302,3 +302,42 @@ def search_for_triangulation(desc1, node1, has_mp1, x1, y1, angle1, desc2, node2
     n = lib().orc_search_for_triangulation(_p(d1), _p(n1), _p(h1), _p(xx1), _p(yy1), _p(a1), len(d1), _p(d2), _p(n2), _p(h2), _p(xx2), _p(yy2),
                                            _p(a2), _p(o2), len(d2), _p(F), C.c_float(ex), C.c_float(ey), _p(sf), _p(s2), int(check_ori), _p(m12))
     return n, m12[:len(d1)].copy()
+
+
+class Voc:
+    """orc_voc_* wrappers (bow_oracle.c)."""
+
+    def __init__(self, k, L, parent, desc, weight):
+        self.par = np.ascontiguousarray(parent, "i4"); self.desc = np.ascontiguousarray(desc, np.uint8); self.w = np.ascontiguousarray(weight, "f8")
+        lib().orc_voc_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_voc_create(int(k), int(L), len(self.par), _p(self.par), _p(self.desc), _p(self.w)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_voc_destroy(self.h); self.h = None
+
+    def transform_features(self, feat, levelsup=4):
+        f = np.ascontiguousarray(feat, np.uint8); n = len(f)
+        wid = np.zeros(max(n, 1), "i4"); w = np.zeros(max(n, 1), "f8"); nid = np.zeros(max(n, 1), "i4")
+        lib().orc_voc_transform(self.h, _p(f), n, int(levelsup), _p(wid), _p(w), _p(nid))
+        return wid[:n], w[:n], nid[:n]
+
+
+def bow_vector(word_id, weight, node_id, weighting=0, scoring=0):
+    wid = np.ascontiguousarray(word_id, "i4"); w = np.ascontiguousarray(weight, "f8"); nid = np.ascontiguousarray(node_id, "i4")
+    n = len(wid)
+    oid = np.zeros(max(n, 1), "i4"); oval = np.zeros(max(n, 1), "f8"); fv = np.full(max(n, 1), -1, "i4")
+    m = lib().orc_bow_vector(n, _p(wid), _p(w), _p(nid), int(weighting), int(scoring), _p(oid), _p(oval), _p(fv))
+    return oid[:m].copy(), oval[:m].copy(), fv[:n].copy()
+
+
+def bow_score_l1(a, b):
+    (i1, v1), (i2, v2) = a, b
+    i1 = np.ascontiguousarray(i1, "i4"); v1 = np.ascontiguousarray(v1, "f8"); i2 = np.ascontiguousarray(i2, "i4"); v2 = np.ascontiguousarray(v2, "f8")
+    lib().orc_bow_score_l1.restype = C.c_double
+    return float(lib().orc_bow_score_l1(len(i1), _p(i1), _p(v1), len(i2), _p(i2), _p(v2)))
+
+
+def distinctive_descriptor(desc):
+    d = np.ascontiguousarray(desc, np.uint8)
+    return int(lib().orc_distinctive_descriptor(_p(d), len(d)))

@@ -133,16 +133,22 @@ def main():
     dom_s = kern[dom]["ms_per_step"] * 1e-3
     achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
     traffic = None
+    valu = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            pmc = json.load(open(tpath)).get(dom, {})
+            traffic = pmc.get("hbm_bytes_per_launch")
+            valu = pmc.get("valu_issue_frac")
         except Exception:
             traffic = None
     extract_ms = sum(v["ms_per_step"] for k, v in kern.items() if k != "k_hamming_bf")
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes,
+                # the kernel's real bound is vector-ALU issue (integer FAST test): SQ_INSTS_VALU x 4 cycles / SIMD-cycles of
+                # the same kernel from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), not measured live
+                "valu_issue_frac": valu,
                 "pipeline_algorithmic_GBps": round(ALG_BYTES_FRAME * FRAMES / (extract_ms * 1e-3) / 1e9, 2) if extract_ms else None}
 
     # ---- CPU oracle on this box's host cores (rank 0, N=1 only): the same batch, one core like the reference

@@ -644,7 +644,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_octree: DistributeOctTree (ORBextractor.cpp:707-931), one wave per (frame, level).
+// k_octree: DistributeOctTree (ORBextractor.cpp:707-931), one workgroup of 4 waves per (frame, level): the per-node
+// key loops (child counts, 4-way partition) are dealt to the waves, the list bookkeeping is computed by every wave
+// identically (same LDS values written four times) so that all loop control stays uniform across the block.
 //
 // The reference keeps nodes in a std::list, inserting children with push_front and erasing the
 // parent.  Equivalent array form used here: after a pass in which the nodes P_0..P_{m-1} are divided
@@ -679,7 +681,7 @@ __device__ __forceinline__ OctNodes oct_carve(char* base, int cap)
 __device__ __forceinline__ int key_x(unsigned k) { return (int)(k & 0xFFFu); }
 __device__ __forceinline__ int key_y(unsigned k) { return (int)((k >> 12) & 0xFFFu); }
 
-// The block is ONE wave: this orders the LDS and global accesses of its lanes between phases.
+// Orders the LDS and global accesses of the block's 4 waves between phases.
 __device__ __forceinline__ void wave_sync_mem()
 {
     __threadfence_block();
@@ -691,14 +693,15 @@ __device__ __forceinline__ int oct_nonempty(const int* cc, int p)
     return (cc[4 * p] > 0) + (cc[4 * p + 1] > 0) + (cc[4 * p + 2] > 0) + (cc[4 * p + 3] > 0);
 }
 
-__global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* __restrict__ cells,
+__global__ __launch_bounds__(256) void k_octree(const OrbGeom g, const OrbCell* __restrict__ cells,
                                                const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
                                                unsigned* keysA, unsigned* keysB,
                                                unsigned* __restrict__ out, int* __restrict__ out_count,
                                                int* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int level = blockIdx.x, f = blockIdx.y, lane = lane_id();
+    // blockIdx.y = level: the long-running fine levels are dispatched first
+    const int level = blockIdx.y, f = blockIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
     const OrbLevel& L = g.lv[level];
     const int cap = g.list_cap;                                          // multiple of 16
     OctNodes cur = oct_carve(smem, cap);
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* _
         if (cnt > 0) {
             const unsigned* s = fslots + cells[L.cell_first + ci].slot_first;
             for (int k = 0; k < cnt; k++)
-                if (dst + k < L.key_cap) kb[0][dst + k] = s[k];
+                if (wv == 0 && dst + k < L.key_cap) kb[0][dst + k] = s[k];
         }
         total += __shfl(incl, 63, 64);
     }
@@ -765,12 +768,12 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* _
 #pragma unroll
             for (int q = 0; q < ORB_MAX_ROOTS; q++) {
                 const unsigned long long m = __ballot(r == q);
-                if (r == q) kb[1][run[q] + __popcll(m & lanemask_lt())] = key;
+                if (wv == 0 && r == q) kb[1][run[q] + __popcll(m & lanemask_lt())] = key;
                 run[q] += __popcll(m);
             }
         }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         int p = 0;
 #pragma unroll
         for (int r = 0; r < ORB_MAX_ROOTS; r++) {
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* _
         // (1) child key counts of every node holding more than one key
         for (int p = 0; p < len; p++) {
             const int cnt = cur.count[p];
-            if (cnt <= 1) continue;
+            if (cnt <= 1 || (p & 3) != wv) continue;                          // the nodes are dealt to the 4 waves
             const int sx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;       // x0 + ceil(w/2)  (:652)
             const int sy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
             const unsigned* src = kb[cur.buf[p]] + cur.first[p];
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* _
             newExpand += wave_sum(gt1);
         }
         // (6) stable 4-way partition of each divided node's keys into the other scratch buffer
-        for (int k = 0; k < nd; k++) {
+        for (int k = wv; k < nd; k += 4) {
             const int p = ord[k];
             const int cnt = cur.count[p];
             const int sx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* _
 
     // ---- keep the best response of every node, first key wins ties (:912-928); order = list order
     unsigned* o = out + (long long)f * g.out_per_frame + L.out_first;
-    for (int base = 0; base < len; base += 64) {
+    for (int base = 64 * wv; base < len; base += 256) {
         const int p = base + lane;
         if (p < len && p < L.out_cap) {
             const unsigned* src = kb[cur.buf[p]] + cur.first[p];
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(64) void k_octree(const OrbGeom g, const OrbCell* _
             o[p] = best;
         }
     }
-    if (lane == 0) *ocount = min(len, L.out_cap);
+    if (threadIdx.x == 0) *ocount = min(len, L.out_cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1202,7 +1205,7 @@ void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells
                        const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
                        unsigned* out, int* out_count, int* status)
 {
-    hipLaunchKernelGGL(k_octree, dim3(nlevels, nframes), dim3(64), orb_octree_lds_bytes(list_cap), s,
+    hipLaunchKernelGGL(k_octree, dim3(nframes, nlevels), dim3(256), orb_octree_lds_bytes(list_cap), s,
                        g_dev, cells, slots, cell_count, keysA, keysB, out, out_count, status);
 }
 void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_frame, int nframes, const unsigned* sel,

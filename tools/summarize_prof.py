@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output under gpurun_out/ into the tracked summaries under profiles/.
 
-usage: summarize_prof.py TAG KT_DIR [FETCH_DIR WRITE_DIR]
+usage: summarize_prof.py TAG KT_DIR [FETCH_DIR WRITE_DIR [SQ_DIR]]
   KT_DIR     rocprofv3 --kernel-trace --stats --output-format csv
   FETCH_DIR  rocprofv3 --pmc FETCH_SIZE  (own pass)      WRITE_DIR  rocprofv3 --pmc WRITE_SIZE (own pass)
+  SQ_DIR     rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE (own pass)
 Writes profiles/TAG_kernel_stats.csv, and profiles/pmc_traffic.json (read by bench.py's roofline.traffic).
 HBM bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024: FETCH_SIZE/WRITE_SIZE are in KiB, and gfx950's
 FETCH_SIZE counts half the bytes of a streamed read (MI355X_MICROARCH.md, section HBM).
@@ -18,7 +19,7 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 def short(name):
     n = name.split("(")[0]
     if n.startswith("void "): n = n[5:]
-    return n[:70]
+    return n.split("<")[0][:70]                       # template arguments dropped: one entry per kernel
 
 rows = []
 for f in glob.glob(os.path.join(kt, "**", "*_kernel_stats.csv"), recursive=True):
@@ -49,5 +50,19 @@ if len(sys.argv) >= 5:
         out[k] = {"fetch_size_kib_per_launch": round(f, 1), "write_size_kib_per_launch": round(w, 1),
                   "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024), "launches_sampled": fe[k][1],
                   "note": "FETCH_SIZE x2 (gfx950 correction for streamed reads; uncalibrated for byte-wide loads) + WRITE_SIZE"}
+    if len(sys.argv) >= 6:
+        # vector-ALU issue utilisation: a wave64 VALU instruction holds its SIMD for >= 4 cycles and the chip has
+        # 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        names = ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"]
+        sq = {nm: counter(sys.argv[5], nm) for nm in names}
+        for k in sorted(set(sq["SQ_INSTS_VALU"])):
+            if not k.startswith("k_"): continue
+            m = {nm: sq[nm][k][0] / max(sq[nm][k][1], 1) for nm in names}
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+            e = out.setdefault(k, {})
+            e.update({"valu_insts_per_launch": int(m["SQ_INSTS_VALU"]), "waves_per_launch": int(m["SQ_WAVES"]),
+                      "busy_cycles_per_launch": int(cyc),
+                      "valu_issue_frac": round(m["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 4) if cyc else None,
+                      "wait_any_frac_of_wave_cycles": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 4) if m["SQ_WAVE_CYCLES"] else None})
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    for k, v in out.items(): print(k, v["hbm_bytes_per_launch"])
+    for k, v in out.items(): print(k, v.get("hbm_bytes_per_launch"), v.get("valu_issue_frac"))

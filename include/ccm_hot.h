@@ -359,6 +359,33 @@ typedef struct {
 } ccm_pose_problem;
 int ccm_pose_optimize(ccm_ctx*, ccm_pose_problem*);
 
+/* Optimizer::OptimizeSim3(pKF1, pKF2, vpMatches1, g2oS12, th2, bFixScale) (src/Optimizer.cpp:867-1062), next row F4,
+ * batched over candidate keyframe pairs: one VertexSim3Expmap, fixed points, EdgeSim3ProjectXYZ +
+ * EdgeInverseSim3ProjectXYZ per correspondence with g2o's numeric Jacobians (delta 1e-9) and Huber(sqrt(th2));
+ * optimize(5), prune chi2 > th2, optimize(5 or 10), classify.  Correspondence e of problem p (first[p] <= e <
+ * first[p+1]) = one non-null vpMatches1[i] that passed :918-943: P1 = R1w*P3D1w + t1w, P2 = R2w*P3D2w + t2w (the
+ * caller's float arithmetic, widened), obs1/info1 = pKF1->mvKeysUn[i] / mvInvLevelSigma2, obs2/info2 likewise for
+ * i2.  sim3 = g2oS12 as qx,qy,qz,qw, tx,ty,tz, s (in/out; untouched when fewer than 10 correspondences survive the
+ * first round, where the reference returns 0); inlier[e] = vpMatches1 entry kept; n_inliers[p] = the return value. */
+typedef struct {
+    int32_t        n_problems;
+    double*        sim3;       /* [n_problems][8] in/out */
+    const int32_t* fix_scale;  /* [n_problems] */
+    const double*  K1;         /* [n_problems][4] fx, fy, cx, cy of pKF1 */
+    const double*  K2;
+    const int32_t* first;      /* [n_problems+1] */
+    const double*  P1;         /* [..][3] */
+    const double*  P2;
+    const double*  obs1;       /* [..][2] */
+    const double*  obs2;
+    const double*  info1;      /* [..] */
+    const double*  info2;
+    const float*   th2;        /* [n_problems] */
+    uint8_t*       inlier;     /* [..] out */
+    int32_t*       n_inliers;  /* [n_problems] out */
+} ccm_sim3_problem;
+int ccm_optimize_sim3(ccm_ctx*, ccm_sim3_problem*);
+
 /* Multi-GPU GBA: every rank calls ccm_ba_solve with the
  * SAME poses and ITS OWN landmark partition (points + their edges); the reduced
  * camera system is summed with one RCCL all-reduce per LM trial.  One rank

@@ -40,6 +40,7 @@ void ccm_destroy(ccm_ctx* c)
     match_state_free(c->match);
     ba_state_free(c->ba);
     pose_state_free(c->pose);
+    sim3_state_free(c->sim3);
     for (ProfLabel& L : c->prof) for (auto& e : L.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

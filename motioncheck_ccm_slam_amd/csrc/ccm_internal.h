@@ -14,6 +14,7 @@ struct MatchState;
 struct BaState;
 struct CommState;
 struct PoseState;
+struct Sim3State;
 
 struct ProfLabel { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
 
@@ -28,6 +29,7 @@ struct ccm_ctx {
     BaState* ba = nullptr;
     CommState* comm = nullptr;
     PoseState* pose = nullptr;
+    Sim3State* sim3 = nullptr;
 };
 
 // grow-only device buffer
@@ -88,3 +90,4 @@ void match_state_free(MatchState*);
 void ba_state_free(BaState*);
 void comm_state_free(ccm_ctx*);
 void pose_state_free(PoseState*);
+void sim3_state_free(Sim3State*);

@@ -85,6 +85,24 @@ class Optimizer:
         return poses, outl[:len(info)], ninl
 
 
+    @staticmethod
+    def OptimizeSim3(sim3, fix_scale, K1, K2, first, P1, P2, obs1, obs2, info1, info2, th2, ctx=None):
+        """Batched Optimizer::OptimizeSim3 (src/Optimizer.cpp:867-1062).  sim3 [n][8] = qx,qy,qz,qw,tx,ty,tz,s.
+        Returns (sim3, inlier flags per correspondence, nIn per problem)."""
+        ctx = ctx or _lib.default_context(0)
+        lib = _lib.load()
+        a = np.ascontiguousarray
+        s3 = a(sim3, "f8").copy().reshape(-1, 8); n = len(s3)
+        fs = a(np.broadcast_to(fix_scale, n), "i4"); k1 = a(K1, "f8"); k2 = a(K2, "f8"); fr = a(first, "i4")
+        A = [a(P1, "f8"), a(P2, "f8"), a(obs1, "f8"), a(obs2, "f8"), a(info1, "f8"), a(info2, "f8")]
+        t2 = a(np.broadcast_to(th2, n), "f4")
+        inl = np.zeros(max(len(A[4]), 1), np.uint8); nin = np.zeros(n, "i4")
+        p = _lib.ptr
+        pb = _lib.Sim3Problem(n, p(s3), p(fs), p(k1), p(k2), p(fr), *[p(x) for x in A], p(t2), p(inl), p(nin))
+        ctx.check(lib.ccm_optimize_sim3(ctx.handle, C.byref(pb)))
+        return s3, inl[:len(A[4])], nin
+
+
 def pose_from_mat4f(T: np.ndarray) -> np.ndarray:
     T = np.ascontiguousarray(T, np.float32); out = np.zeros(7)
     _lib.load().ccm_pose_from_mat4f(_lib.ptr(T), _lib.ptr(out))

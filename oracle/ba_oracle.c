@@ -649,3 +649,219 @@ int orc_pose_optimize(double* pose7, const double* intr4, int n, const double* p
     *n_inliers = n - nBadEdges;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * F4 (first half): Optimizer::OptimizeSim3 (cslam/src/Optimizer.cpp:867-1062).
+ * One VertexSim3Expmap (types_seven_dof_expmap.h:52-107, Sim3 = sim3.h), fixed points, two edges per
+ * correspondence: EdgeSim3ProjectXYZ (:146-166) and EdgeInverseSim3ProjectXYZ (:169-189), whose Jacobians g2o takes
+ * numerically (base_binary_edge.hpp:147-196: central differences, delta 1e-9); Huber(sqrt(th2)) on every edge;
+ * BlockSolverX + LinearSolverDense (7x7 LDLT) + Levenberg: optimize(5), drop the pairs with chi2 > th2, optimize(5
+ * or 10), classify again.  sim3 = qx,qy,qz,qw, tx,ty,tz, s. */
+static void rotv(const double* q, const double* v, double* o)
+{
+    double R[9]; quat_to_R(q, R);
+    for (int i = 0; i < 3; i++) o[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+/* Sim3(const Vector7d& update), sim3.h:62-131 */
+void orc_sim3_exp(const double* u, double* S)
+{
+    const double* omega = u; const double* upsilon = u + 3;
+    const double sigma = u[6];
+    const double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
+    const double Om[9] = { 0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0 };
+    double Om2[9]; mat3_mul(Om, Om, Om2);
+    const double s = exp(sigma);
+    const double eps = 0.00001;
+    double A, B, C, R[9];
+    const double I[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    if (fabs(sigma) < eps) {
+        C = 1;
+        if (theta < eps) { A = 1. / 2.; B = 1. / 6.; for (int i = 0; i < 9; i++) R[i] = I[i] + Om[i] + Om2[i]; }
+        else {
+            const double theta2 = theta * theta;
+            A = (1 - cos(theta)) / theta2;
+            B = (theta - sin(theta)) / (theta2 * theta);
+            for (int i = 0; i < 9; i++) R[i] = I[i] + sin(theta) / theta * Om[i] + (1 - cos(theta)) / (theta * theta) * Om2[i];
+        }
+    } else {
+        C = (s - 1) / sigma;
+        if (theta < eps) {
+            const double sigma2 = sigma * sigma;
+            A = ((sigma - 1) * s + 1) / sigma2;
+            B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
+            for (int i = 0; i < 9; i++) R[i] = I[i] + Om[i] + Om2[i];
+        } else {
+            for (int i = 0; i < 9; i++) R[i] = I[i] + sin(theta) / theta * Om[i] + (1 - cos(theta)) / (theta * theta) * Om2[i];
+            const double a = s * sin(theta), b = s * cos(theta);
+            const double theta2 = theta * theta, sigma2 = sigma * sigma;
+            const double c = theta2 + sigma2;
+            A = (a * sigma + (1 - b) * theta) / (theta * c);
+            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+        }
+    }
+    R_to_quat(R, S);
+    for (int i = 0; i < 3; i++) {
+        S[4 + i] = 0;
+        for (int j = 0; j < 3; j++) S[4 + i] += (A * Om[3 * i + j] + B * Om2[3 * i + j] + C * I[3 * i + j]) * upsilon[j];
+    }
+    S[7] = s;
+}
+/* Sim3::operator*, sim3.h:277-283 */
+void orc_sim3_mul(const double* a, const double* b, double* o)
+{
+    double q[4], t[3];
+    quat_mul(a, b, q);
+    rotv(a, b + 4, t);
+    for (int i = 0; i < 4; i++) o[i] = q[i];
+    for (int i = 0; i < 3; i++) o[4 + i] = a[7] * t[i] + a[4 + i];
+    o[7] = a[7] * b[7];
+}
+/* Sim3::inverse, sim3.h:245-248 */
+void orc_sim3_inverse(const double* a, double* o)
+{
+    const double qc[4] = { -a[0], -a[1], -a[2], a[3] };
+    const double ts[3] = { (-1. / a[7]) * a[4], (-1. / a[7]) * a[5], (-1. / a[7]) * a[6] };
+    double t[3]; rotv(qc, ts, t);
+    for (int i = 0; i < 4; i++) o[i] = qc[i];
+    for (int i = 0; i < 3; i++) o[4 + i] = t[i];
+    o[7] = 1. / a[7];
+}
+static void sim3_map(const double* S, const double* x, double* o)
+{
+    double r[3]; rotv(S, x, r);
+    for (int i = 0; i < 3; i++) o[i] = S[7] * r[i] + S[4 + i];
+}
+/* the two edge errors of correspondence e at estimate S (types_seven_dof_expmap.h:155-163, :178-186) */
+static void sim3_errors(const double* S, const double* K1, const double* K2, const double* P1, const double* P2,
+                        const double* obs1, const double* obs2, double* e12, double* e21)
+{
+    double x[3], Si[8];
+    sim3_map(S, P2, x);
+    e12[0] = obs1[0] - ((x[0] / x[2]) * K1[0] + K1[2]);
+    e12[1] = obs1[1] - ((x[1] / x[2]) * K1[1] + K1[3]);
+    orc_sim3_inverse(S, Si);
+    sim3_map(Si, P1, x);
+    e21[0] = obs2[0] - ((x[0] / x[2]) * K2[0] + K2[2]);
+    e21[1] = obs2[1] - ((x[1] / x[2]) * K2[1] + K2[3]);
+}
+static void sim3_oplus(const double* S, const double* upd, int fix_scale, double* o)
+{
+    double u[7]; memcpy(u, upd, sizeof u);
+    if (fix_scale) u[6] = 0;
+    double E[8]; orc_sim3_exp(u, E);
+    orc_sim3_mul(E, S, o);
+}
+
+/* One optimize(iterations) call on the active correspondences; err12/err21 keep the last computed edge errors. */
+static void sim3_lm(double* S, int fix_scale, const double* K1, const double* K2, int n, const uint8_t* active,
+                    const double* P1, const double* P2, const double* obs1, const double* obs2, const double* info1,
+                    const double* info2, double delta, int iterations, double* err12, double* err21)
+{
+    double lambda = 0, ni = 2; int nBad = 0;
+    for (int it = 0; it < iterations; it++) {
+        double H[49], b[7], cur = 0;
+        memset(H, 0, sizeof H); memset(b, 0, sizeof b);
+        int nact = 0;
+        for (int e = 0; e < n; e++) {
+            if (!active[e]) continue;
+            nact++;
+            sim3_errors(S, K1, K2, P1 + 3 * e, P2 + 3 * e, obs1 + 2 * e, obs2 + 2 * e, err12 + 2 * e, err21 + 2 * e);
+            double J12[14], J21[14];                                   /* [row][d] */
+            for (int d = 0; d < 7; d++) {
+                double up[7] = { 0, 0, 0, 0, 0, 0, 0 }, Sp[8], Sm[8], a12[2], a21[2], b12[2], b21[2];
+                up[d] = 1e-9; sim3_oplus(S, up, fix_scale, Sp);
+                sim3_errors(Sp, K1, K2, P1 + 3 * e, P2 + 3 * e, obs1 + 2 * e, obs2 + 2 * e, a12, a21);
+                up[d] = -1e-9; sim3_oplus(S, up, fix_scale, Sm);
+                sim3_errors(Sm, K1, K2, P1 + 3 * e, P2 + 3 * e, obs1 + 2 * e, obs2 + 2 * e, b12, b21);
+                const double scalar = 1.0 / (2 * 1e-9);
+                J12[d] = scalar * (a12[0] - b12[0]); J12[7 + d] = scalar * (a12[1] - b12[1]);
+                J21[d] = scalar * (a21[0] - b21[0]); J21[7 + d] = scalar * (a21[1] - b21[1]);
+            }
+            for (int k = 0; k < 2; k++) {                              /* edge order of the graph: e12 then e21 */
+                const double* er = k == 0 ? err12 + 2 * e : err21 + 2 * e;
+                const double* J = k == 0 ? J12 : J21;
+                const double inf = k == 0 ? info1[e] : info2[e];
+                const double c2 = inf * (er[0] * er[0] + er[1] * er[1]);
+                double r0, r1; huber(c2, delta, &r0, &r1);
+                cur += r0;
+                const double w = r1 * inf, g0 = -inf * er[0] * r1, g1 = -inf * er[1] * r1;
+                for (int i = 0; i < 7; i++) {
+                    b[i] += J[i] * g0 + J[7 + i] * g1;
+                    for (int j = 0; j < 7; j++) H[i * 7 + j] += w * (J[i] * J[j] + J[7 + i] * J[7 + j]);
+                }
+            }
+        }
+        if (nact == 0) break;
+        const double ini = cur;
+        if (it == 0) {
+            double md = 0;
+            for (int j = 0; j < 7; j++) md = fmax(md, fabs(H[8 * j]));
+            lambda = 1e-5 * md; ni = 2; nBad = 0;
+        }
+        double rho = 0; int qmax = 0;
+        do {
+            double save[8]; memcpy(save, S, sizeof save);
+            double Hl[49], x[7] = { 0, 0, 0, 0, 0, 0, 0 };
+            memcpy(Hl, H, sizeof Hl);
+            for (int j = 0; j < 7; j++) Hl[8 * j] += lambda;
+            int ok2 = chol_factor(Hl, 7);
+            if (ok2) { memcpy(x, b, sizeof x); chol_solve(Hl, 7, x); }
+            double temp = DBL_MAX;
+            if (ok2) {
+                double o[8]; sim3_oplus(S, x, fix_scale, o); memcpy(S, o, sizeof o);
+                temp = 0;
+                for (int e = 0; e < n; e++) {
+                    if (!active[e]) continue;
+                    sim3_errors(S, K1, K2, P1 + 3 * e, P2 + 3 * e, obs1 + 2 * e, obs2 + 2 * e, err12 + 2 * e, err21 + 2 * e);
+                    double r0, r1;
+                    huber(info1[e] * (err12[2 * e] * err12[2 * e] + err12[2 * e + 1] * err12[2 * e + 1]), delta, &r0, &r1); temp += r0;
+                    huber(info2[e] * (err21[2 * e] * err21[2 * e] + err21[2 * e + 1] * err21[2 * e + 1]), delta, &r0, &r1); temp += r0;
+                }
+            }
+            double scale = 1e-3;
+            for (int j = 0; j < 7; j++) scale += x[j] * (lambda * x[j] + b[j]);
+            rho = ok2 ? (cur - temp) / scale : -1.0;
+            if (rho > 0 && isfinite(temp)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2; cur = temp;
+            } else { lambda *= ni; ni *= 2; memcpy(S, save, sizeof save); }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0) break;
+        if ((ini - cur) * 1e3 < ini) nBad++; else nBad = 0;
+        if (nBad >= 3) break;
+    }
+}
+
+/* Returns nIn; inlier[e] = the correspondence survives (vpMatches1 entry kept); sim3 is updated unless fewer than 10
+ * correspondences survive the first round (:1022-1023: return 0 before the estimate is read back). */
+int orc_optimize_sim3(double* sim3, int fix_scale, const double* K1, const double* K2, int n, const double* P1, const double* P2,
+                      const double* obs1, const double* obs2, const double* info1, const double* info2, float th2, uint8_t* inlier)
+{
+    double S[8]; memcpy(S, sim3, sizeof S);
+    double* err12 = (double*)calloc(2 * (size_t)(n > 0 ? n : 1), sizeof(double));
+    double* err21 = (double*)calloc(2 * (size_t)(n > 0 ? n : 1), sizeof(double));
+    const double delta = (double)sqrtf(th2);                           /* const float deltaHuber = sqrt(th2), :903 */
+    for (int e = 0; e < n; e++) inlier[e] = 1;
+    sim3_lm(S, fix_scale, K1, K2, n, inlier, P1, P2, obs1, obs2, info1, info2, delta, 5, err12, err21);
+    int nBad = 0;
+    for (int e = 0; e < n; e++) {
+        const double c12 = info1[e] * (err12[2 * e] * err12[2 * e] + err12[2 * e + 1] * err12[2 * e + 1]);
+        const double c21 = info2[e] * (err21[2 * e] * err21[2 * e] + err21[2 * e + 1] * err21[2 * e + 1]);
+        if (c12 > th2 || c21 > th2) { inlier[e] = 0; nBad++; }
+    }
+    const int more = nBad > 0 ? 10 : 5;
+    if (n - nBad < 10) { free(err12); free(err21); return 0; }
+    sim3_lm(S, fix_scale, K1, K2, n, inlier, P1, P2, obs1, obs2, info1, info2, delta, more, err12, err21);
+    int nIn = 0;
+    for (int e = 0; e < n; e++) {
+        if (!inlier[e]) continue;
+        const double c12 = info1[e] * (err12[2 * e] * err12[2 * e] + err12[2 * e + 1] * err12[2 * e + 1]);
+        const double c21 = info2[e] * (err21[2 * e] * err21[2 * e] + err21[2 * e + 1] * err21[2 * e + 1]);
+        if (c12 > th2 || c21 > th2) inlier[e] = 0; else nIn++;
+    }
+    memcpy(sim3, S, sizeof S);
+    free(err12); free(err21);
+    return nIn;
+}

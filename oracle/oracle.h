@@ -138,4 +138,11 @@ int  orc_ba_reduced_system(const orc_ba_problem*, double huber_delta, double lam
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- F4: Optimizer::OptimizeSim3 (ba_oracle.c) ---- */
+void orc_sim3_exp(const double* update7, double* sim3);
+void orc_sim3_mul(const double* a, const double* b, double* o);
+void orc_sim3_inverse(const double* a, double* o);
+int orc_optimize_sim3(double* sim3, int fix_scale, const double* K1, const double* K2, int n, const double* P1, const double* P2,
+                      const double* obs1, const double* obs2, const double* info1, const double* info2, float th2, uint8_t* inlier);
 #endif

@@ -341,3 +341,30 @@ def bow_score_l1(a, b):
 def distinctive_descriptor(desc):
     d = np.ascontiguousarray(desc, np.uint8)
     return int(lib().orc_distinctive_descriptor(_p(d), len(d)))
+
+
+def optimize_sim3(sim3, fix_scale, K1, K2, P1, P2, obs1, obs2, info1, info2, th2):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    s = a(sim3, "f8").copy(); k1 = a(K1, "f8"); k2 = a(K2, "f8")
+    A = [a(P1, "f8"), a(P2, "f8"), a(obs1, "f8"), a(obs2, "f8"), a(info1, "f8"), a(info2, "f8")]
+    n = len(A[4]); inl = np.zeros(max(n, 1), np.uint8)
+    nin = lib().orc_optimize_sim3(_p(s), int(fix_scale), _p(k1), _p(k2), n, *[_p(x) for x in A], C.c_float(th2), _p(inl))
+    return s, inl[:n].copy(), nin
+
+
+def sim3_exp(u):
+    u = np.ascontiguousarray(u, "f8"); o = np.zeros(8)
+    lib().orc_sim3_exp(_p(u), _p(o))
+    return o
+
+
+def sim3_mul(a, b):
+    a = np.ascontiguousarray(a, "f8"); b = np.ascontiguousarray(b, "f8"); o = np.zeros(8)
+    lib().orc_sim3_mul(_p(a), _p(b), _p(o))
+    return o
+
+
+def sim3_inverse(a):
+    a = np.ascontiguousarray(a, "f8"); o = np.zeros(8)
+    lib().orc_sim3_inverse(_p(a), _p(o))
+    return o

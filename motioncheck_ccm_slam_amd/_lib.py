@@ -78,7 +78,7 @@ class Sim3Problem(C.Structure):
 
 class BaOptions(C.Structure):
     _fields_ = [("iterations", C.c_int), ("huber_delta", C.c_double), ("iterations2", C.c_int),
-                ("outlier_chi2", C.c_double), ("stop_flag", C.c_void_p)]
+                ("outlier_chi2", C.c_double), ("stop_flag", C.c_void_p), ("pcg_tol", C.c_double)]
 
 
 class BaResult(C.Structure):

@@ -21,7 +21,7 @@ TH_HUBER_2D_LOCAL = float(np.sqrt(5.991))    # src/Optimizer.cpp:468
 CHI2_MONO = 5.991                            # src/Optimizer.cpp:556, :582
 
 
-def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None):
+def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None, pcg_tol=0.0):
     lib = _lib.load()
     keep = dict(
         poses=np.ascontiguousarray(graph["poses"], "f8").copy(), fixed=np.ascontiguousarray(graph["fixed"], np.uint8),
@@ -34,7 +34,7 @@ def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None):
                    p(keep["edge_pose"]), p(keep["edge_point"]), p(keep["obs"]), p(keep["info"]))
     outl = np.zeros(max(len(keep["edge_pose"]), 1), np.uint8)
     flag = None if stop_flag is None else np.ascontiguousarray(stop_flag, np.uint8)
-    opt = BaOptions(int(iterations), float(huber), int(iterations2), CHI2_MONO, p(flag))
+    opt = BaOptions(int(iterations), float(huber), int(iterations2), CHI2_MONO, p(flag), float(pcg_tol))
     res = BaResult()
     res.edge_outlier = p(outl)
     ctx.check(lib.ccm_ba_solve(ctx.handle, C.byref(pb), C.byref(opt), C.byref(res)))
@@ -63,9 +63,9 @@ class Optimizer:
         return _solve(ctx, graph, 5, TH_HUBER_2D_LOCAL, 10, pbStopFlag)
 
     @staticmethod
-    def MapFusionGBA(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None):
+    def MapFusionGBA(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None, pcg_tol: float = 0.0):
         ctx = ctx or _lib.default_context(0)
-        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag)
+        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag, pcg_tol)
 
 
     @staticmethod

@@ -66,7 +66,8 @@ int ccm_hamming_match_dev(ccm_ctx* c, const uint8_t* q_dev, int nq, size_t q_pai
     // Few pairs cannot fill 256 CUs with one workgroup each: split the train rows of a pair over several
     // workgroups (exact merge afterwards) until there are about four workgroups per CU.
     static const int env_split = getenv("CCM_BF_SPLIT") ? atoi(getenv("CCM_BF_SPLIT")) : 0;
-    static const int variant = getenv("CCM_BF_VARIANT") ? atoi(getenv("CCM_BF_VARIANT")) : 0;
+    // default: the matrix-core kernel (variant 3) while its per-train table fits LDS (nt <= 2048), else the VALU kernel
+    static const int variant = getenv("CCM_BF_VARIANT") ? atoi(getenv("CCM_BF_VARIANT")) : 3;
     int n_split = env_split > 0 ? env_split : 1;
     if (env_split <= 0) while (n_split < 8 && (long long)n_pairs * n_split < 1024 && nt / (n_split * 2) >= 128) n_split *= 2;
     if (n_split > 1) {

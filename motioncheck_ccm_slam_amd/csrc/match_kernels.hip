@@ -1,6 +1,7 @@
 // match_kernels.hip -- 256-bit Hamming matching on CDNA4.
-//   k_hamming_bf      brute-force best / second-best per query (inner loop of ORBmatcher::SearchByBoW,
-//                     cslam/src/ORBmatcher.cpp:224-245, with every feature in one vocabulary node)
+//   k_hamming_mfma    brute-force best / second-best per query on the matrix cores (<= 2048 train rows per pair)
+//   k_hamming_bf      the same on the vector ALU (any size): inner loop of ORBmatcher::SearchByBoW,
+//                     cslam/src/ORBmatcher.cpp:224-245, with every feature in one vocabulary node
 //   k_hamming_ranges  distances of each side-1 feature to its vocabulary node's side-2 features
 //                     (the DescriptorDistance calls of SearchByBoW; the greedy acceptance stays on the host)
 // DescriptorDistance (:1653-1669) is popcount(a^b) over 8 dwords: v_xor_b32 + v_bcnt_u32_b32 with accumulate.
@@ -95,6 +96,153 @@ __global__ __launch_bounds__(THREADS) void k_hamming_bf(
                 best_dist[o] = live ? (int)(best[k] >> 16) : 256;
                 second_dist[o] = live ? sec[k] : 256;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hamming_mfma: the same best / second-best search on the matrix cores.
+//   hamming(a, b) = popc(a) + popc(b) - 2 <a, b>   with <a, b> the dot product of the 0/1 bit vectors,
+// so a 32 x 32 block of distances is eight v_mfma_i32_32x32x32_i8 (K = 256 bits) on operands whose bits are
+// expanded to bytes: train rows to 0/1, query columns to 0/-1, which leaves -<a, b> in the accumulator.
+// Layout: A operand = 32 train rows, B operand = 32 query columns.  C/D puts column j = lane & 31 on the lane and
+// rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) in its 16 registers, i.e. a lane sees ONE query and 16 trains per
+// tile, so the running (best, second) of that query are two registers per lane.  The running state is the signed key
+//   ((popc(b) - 2 <a, b>) << 16) + train index = (acc << 17) + w[row]      (one v_lshl_add_u32)
+// -- popc(a) is constant per lane and added at the end -- folded with  second = med3(best, second, key);
+// best = min(best, key): three VALU instructions per distance instead of ~18, the rest is MFMA.
+// A/B fragments: lane (h = lane >> 5, r = lane & 31) supplies the 16 bytes of k-step s from bits [32 s + 16 h,
+// 32 s + 16 h + 16) of its row / column; A and B use the same k assignment, which is all the dot product needs.
+// One workgroup = 4 waves x 64 queries; the 0/1 train fragments of a 32-train tile (8 KiB) are expanded once per
+// workgroup into LDS (double-buffered) and read back as ds_read_b128.
+typedef int hm_v4i __attribute__((ext_vector_type(4)));
+typedef int hm_v16i __attribute__((ext_vector_type(16)));
+#define HM_QW 64                 // queries per wave (two 32-column blocks)
+#define HM_WAVES 4
+#define HM_SENT 0x3FFFFFFF       // key of "no train": larger than every real key, index field 0xFFFF
+#define HM_MAX_NT 2048           // train rows whose row words fit the LDS table (the launcher falls back beyond)
+
+__device__ __forceinline__ hm_v4i hm_expand16(unsigned hw, unsigned mul)
+{
+    // 4 bits -> 4 bytes: n * 0x204081 puts bit i at bit 8 i; mul = 1 gives 0/1 bytes, mul = 255 gives 0/0xFF (-1)
+    hm_v4i v;
+    // (x << 8) - x = 255 x without a 32-bit multiply; the 24-bit multiply is exact (n < 16)
+    unsigned b0 = __umul24((hw >> 0) & 15u, 0x204081u) & 0x01010101u, b1 = __umul24((hw >> 4) & 15u, 0x204081u) & 0x01010101u;
+    unsigned b2 = __umul24((hw >> 8) & 15u, 0x204081u) & 0x01010101u, b3 = __umul24((hw >> 12) & 15u, 0x204081u) & 0x01010101u;
+    if (mul == 255u) { b0 = (b0 << 8) - b0; b1 = (b1 << 8) - b1; b2 = (b2 << 8) - b2; b3 = (b3 << 8) - b3; }
+    v.x = (int)b0; v.y = (int)b1; v.z = (int)b2; v.w = (int)b3;
+    return v;
+}
+
+// 4 workgroups per CU (<= 128 registers per lane): 255 pairs x 4 live query blocks = 1020 workgroups fit in ONE round
+__global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
+    const uint8_t* __restrict__ q, long long q_pair_bytes, const uint8_t* __restrict__ t, long long t_pair_bytes,
+    int nq, int nt, const int* __restrict__ nq_n, const int* __restrict__ nt_n, int q_blocks,
+    int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_dist)
+{
+    __shared__ hm_v4i frag[2][8][64];          // [buffer][k-step][lane]: 16 expanded bytes
+    __shared__ __attribute__((aligned(16))) int wall[HM_MAX_NT];   // per train: (popc << 16) | index, HM_SENT past the live count
+    const int pair = blockIdx.x / q_blocks, qblk = blockIdx.x - pair * q_blocks;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, r = lane & 31;
+    const int nqp = nq_n ? min(max(nq_n[pair], 0), nq) : nq;
+    const int ntp = nt_n ? min(max(nt_n[pair], 0), nt) : nt;
+    const unsigned* qp = reinterpret_cast<const unsigned*>(q + (long long)pair * q_pair_bytes);
+    const unsigned* tp = reinterpret_cast<const unsigned*>(t + (long long)pair * t_pair_bytes);
+    const int q0 = qblk * (HM_QW * HM_WAVES) + wv * HM_QW;              // this wave's first query
+    if (qblk * (HM_QW * HM_WAVES) >= nqp) {                              // whole block past the live queries: defaults only
+        for (int i = tid; i < HM_QW * HM_WAVES; i += 64 * HM_WAVES) {
+            const int qi = qblk * (HM_QW * HM_WAVES) + i;
+            if (qi < nq) { const long long o = (long long)pair * nq + qi; best_idx[o] = -1; best_dist[o] = 256; second_dist[o] = 256; }
+        }
+        return;
+    }
+
+    // ---- B fragments of the wave's 64 queries (0 / -1 bytes) and their popcounts, kept in registers
+    hm_v4i bq[2][8];
+    int pa[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const int qi = q0 + 32 * cb + r;
+        unsigned d[8];
+        int pc = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) { d[s] = qi < nqp ? qp[8 * (long long)qi + s] : 0u; pc += __popc(d[s]); }
+        pa[cb] = pc;
+#pragma unroll
+        for (int s = 0; s < 8; s++) bq[cb][s] = hm_expand16((d[s] >> (16 * h)) & 0xFFFFu, 255u);
+    }
+    int m1[2] = { HM_SENT, HM_SENT }, m2[2] = { HM_SENT, HM_SENT };
+
+    // ---- staging of one 32-train tile: thread p expands dword s = p >> 5 of train r = p & 31 into the two
+    //      lane-half fragments of k-step s; threads 0..31 also make the row words.  The raw words are fetched one
+    //      tile ahead (issued before the MFMAs of the current tile) so that no wave waits on a global load.
+    auto fetch = [&](int tile) {
+        const int tr = tile * 32 + (tid & 31);
+        return tr < ntp ? tp[8 * (long long)tr + (tid >> 5)] : 0u;
+    };
+    auto stage = [&](unsigned dw, int buf) {
+        const int s = tid >> 5;
+        frag[buf][s][tid & 31] = hm_expand16(dw & 0xFFFFu, 1u);
+        frag[buf][s][32 + (tid & 31)] = hm_expand16(dw >> 16, 1u);
+    };
+    // row words of all trains, once per workgroup
+    for (int tr = tid; tr < ((ntp + 31) & ~31); tr += 64 * HM_WAVES) {
+        int w = HM_SENT;
+        if (tr < ntp) {
+            const uint4* d = reinterpret_cast<const uint4*>(tp + 8 * (long long)tr);
+            const uint4 d0 = d[0], d1 = d[1];
+            const int pb = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
+            w = (pb << 16) | tr;
+        }
+        wall[tr] = w;
+    }
+    const int ntiles = (ntp + 31) >> 5;
+    const bool wave_live = q0 < nqp;                                    // waves past the live queries only help staging
+    unsigned nxt = fetch(0);
+    if (ntiles > 0) stage(nxt, 0);
+    nxt = fetch(1);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) stage(nxt, buf ^ 1);
+        if (tile + 2 < ntiles) nxt = fetch(tile + 2);
+        if (wave_live) {
+            hm_v16i acc0 = {}, acc1 = {};
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const hm_v4i a = frag[buf][s][lane];
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const hm_v4i w4 = *reinterpret_cast<const hm_v4i*>(&wall[32 * tile + 8 * g + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int k0 = (int)(((unsigned)acc0[4 * g + e] << 17) + (unsigned)w4[e]);
+                    const int k1 = (int)(((unsigned)acc1[4 * g + e] << 17) + (unsigned)w4[e]);
+                    m2[0] = max(min(m1[0], m2[0]), min(max(m1[0], m2[0]), k0)); m1[0] = min(m1[0], k0);     // v_med3_i32, v_min_i32
+                    m2[1] = max(min(m1[1], m2[1]), min(max(m1[1], m2[1]), k1)); m1[1] = min(m1[1], k1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the two lane halves saw disjoint trains of the same query: merge, add popc(query), write
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const int o1 = __shfl_xor(m1[cb], 32, 64), o2 = __shfl_xor(m2[cb], 32, 64);
+        const int b1 = min(m1[cb], o1);
+        const int b2 = min(max(m1[cb], o1), min(m2[cb], o2));
+        const int qi = q0 + 32 * cb + r;
+        if (h == 0 && qi < nq) {
+            const long long o = (long long)pair * nq + qi;
+            const bool live = qi < nqp;
+            const bool has1 = live && (b1 & 0xFFFF) != 0xFFFF, has2 = live && (b2 & 0xFFFF) != 0xFFFF;
+            const int bd = has1 ? (b1 >> 16) + pa[cb] : 256;
+            best_idx[o] = bd < 256 ? (b1 & 0xFFFF) : -1;           // the reference starts at 256 and compares with <
+            best_dist[o] = bd;
+            second_dist[o] = has2 ? (b2 >> 16) + pa[cb] : 256;
         }
     }
 }
@@ -214,6 +362,12 @@ void match_launch_bf(hipStream_t s, const uint8_t* q, long long q_pair_bytes, co
                      int nq, int nt, int n_pairs, const int* nq_n, const int* nt_n, int n_split, int variant,
                      unsigned* part_best, int* part_second, int* bi, int* bd, int* sd)
 {
+    if (variant == 3 && nt <= HM_MAX_NT) {
+        const int q_blocks = (nq + HM_QW * HM_WAVES - 1) / (HM_QW * HM_WAVES);
+        hipLaunchKernelGGL(k_hamming_mfma, dim3(n_pairs * q_blocks), dim3(64 * HM_WAVES), 0, s, q, q_pair_bytes, t, t_pair_bytes, nq, nt, nq_n, nt_n,
+                           q_blocks, bi, bd, sd);
+        return;
+    }
     const dim3 grid(n_pairs * n_split);
     if (variant == 1)
         hipLaunchKernelGGL((k_hamming_bf<256, 4>), grid, dim3(256), 0, s, q, q_pair_bytes, t, t_pair_bytes, nq, nt, nq_n, nt_n, n_split, part_best, part_second, bi, bd, sd);

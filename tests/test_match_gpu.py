@@ -56,6 +56,23 @@ def test_ragged_empty_and_tiled(ctx, oracle):
     assert (bi == -1).all() and (bd == 256).all()
 
 
+def test_ragged_counts_below_2048_trains(ctx, oracle):
+    """The matrix-core kernel's range (<= 2048 train rows): partial last tiles, dead query blocks, one train, none."""
+    m = ORBmatcher(ctx=ctx)
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (6, 1100, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (6, 1500, 32), dtype=np.uint8)
+    t[0, 40] = q[0, 3]; t[0, 900] = q[0, 3]                         # duplicate best: the lower index wins, second = 0
+    nq_n = np.array([1100, 257, 1, 0, 700, 64]); nt_n = np.array([1500, 33, 1, 77, 0, 1024])
+    bi, bd, sd = m.BruteForce(q, t, nq_n, nt_n)
+    for p in range(6):
+        rbi, rbd, rsd = oracle.hamming_match(q[p, :nq_n[p]], t[p, :nt_n[p]])
+        assert (bi[p, :nq_n[p]] == rbi).all() and (bd[p, :nq_n[p]] == rbd).all() and (sd[p, :nq_n[p]] == rsd).all(), p
+        assert (bi[p, nq_n[p]:] == -1).all() and (bd[p, nq_n[p]:] == 256).all() and (sd[p, nq_n[p]:] == 256).all()
+    assert bi[0, 3] == 40 and bd[0, 3] == 0 and sd[0, 3] == 0
+    assert (sd[2, :1] == 256).all() and (bi[4, :700] == -1).all()
+
+
 def test_many_pairs_property(ctx, oracle):
     """A slice of config 3 (10k pairs in the bench): 512 pairs, symmetric checks on all, oracle on a sample."""
     m = ORBmatcher(0.7, ctx=ctx)

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Throughput of the "next" rows (F1 windowed matchers, F2 pose-only optimisation, F3 vocabulary
+tree, F4 OptimizeSim3) through the C ABI, with the CPU oracle timed on a bounded sample beside each.  Host buffers go in
+and come out (these entry points take what the reference's callers hold), so the figures include PCIe and the host-side
+acceptance loops.  Prints one JSON object; run on the GPU box:  python tools/bench_next.py > gpurun_out/next_rows.json"""
+import json, os, sys, time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from motioncheck_ccm_slam_amd import _lib, synth                       # noqa: E402
+from motioncheck_ccm_slam_amd.matcher import FrameGridView, ORBmatcher  # noqa: E402
+from motioncheck_ccm_slam_amd.optimizer import Optimizer                # noqa: E402
+from motioncheck_ccm_slam_amd.orb import ORBextractor                   # noqa: E402
+from motioncheck_ccm_slam_amd.vocabulary import ORBVocabulary, synthetic_tree  # noqa: E402
+from oracle import oracle_py as O                                       # noqa: E402  (checker / CPU baseline only)
+from sim3_problems import make_problem                                  # noqa: E402
+
+
+def timed(fn, reps=5):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+ctx = _lib.Context(0)
+out = {}
+ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+kps, desc = ex(synth.frame(0))
+fr = FrameGridView(kps["x"], kps["y"], kps["octave"], desc)
+sf = ex.GetScaleFactors(); n = len(fr.kx)
+rng = np.random.default_rng(0)
+m = ORBmatcher(0.8, ctx=ctx)
+
+# F1: SearchByProjection(Frame, map points): 2000 map points against one frame
+nmp = 2000
+src = rng.integers(0, n, nmp)
+mp_desc = desc[src] ^ np.packbits(rng.random((nmp, 256)) < 0.05, axis=1, bitorder="little")
+px = (fr.kx[src] + rng.normal(0, 1.5, nmp)).astype("f4"); py = (fr.ky[src] + rng.normal(0, 1.5, nmp)).astype("f4")
+lvl = np.clip(fr.oct[src] + rng.integers(0, 2, nmp), 0, 7); vc = rng.uniform(0.99, 1, nmp).astype("f4")
+ones = np.ones(nmp, np.uint8); occ = np.zeros(n, np.uint8)
+t_gpu = timed(lambda: m.SearchByProjection(fr, sf, ones, lvl, vc, px, py, mp_desc, ones, occ, 3.0))
+t_cpu = timed(lambda: O.search_by_projection(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, ones, lvl, vc, px, py, mp_desc, ones, occ, 3.0, 0.8), 3)
+out["F1_search_by_projection"] = {"map_points": nmp, "frame_features": n, "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms": round(t_cpu * 1e3, 3)}
+
+# F1 primitive: 20000 window queries (10 frames' worth) in one call
+nq = 20000
+qx = rng.uniform(0, 752, nq).astype("f4"); qy = rng.uniform(0, 480, nq).astype("f4"); qr = np.full(nq, 15.0, "f4")
+neg = np.full(nq, -1, "i4"); qd = desc[rng.integers(0, n, nq)]
+t_gpu = timed(lambda: m.FeaturesInArea(fr, qx, qy, qr, neg, neg, qd, cap=128))
+t0 = time.perf_counter()
+for i in range(2000):
+    O.features_in_area(fr.kx, fr.ky, fr.oct, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, qx[i], qy[i], qr[i], -1, -1)
+t_cpu = (time.perf_counter() - t0) * (nq / 2000)
+out["F1_window_candidates"] = {"queries": nq, "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms_scaled_from_2000": round(t_cpu * 1e3, 1),
+                               "note": "CPU figure is the list only (no distances) through a Python loop"}
+
+# F2: pose-only optimisation, 256 frames x 300 correspondences
+F, per = 256, 300
+poses = np.tile(np.array([0, 0, 0, 1, 0, 0, 0.0]), (F, 1)); intr = np.tile(np.array([458.654, 457.296, 367.215, 248.375]), (F, 1))
+pts = np.stack([rng.uniform(-2, 2, F * per), rng.uniform(-1.5, 1.5, F * per), rng.uniform(3, 9, F * per)], 1)
+obs = np.stack([pts[:, 0] / pts[:, 2] * 458.654 + 367.215, pts[:, 1] / pts[:, 2] * 457.296 + 248.375], 1) + rng.normal(0, 0.7, (F * per, 2))
+poses[:, 4:] += rng.normal(0, 0.03, (F, 3))
+info = np.ones(F * per); first = (np.arange(F + 1) * per).astype("i4")
+t_gpu = timed(lambda: Optimizer.PoseOptimizationClient(poses, intr, first, pts, obs, info, ctx=ctx))
+t_cpu = timed(lambda: [O.pose_optimize(poses[f], intr[f], pts[f * per:(f + 1) * per], obs[f * per:(f + 1) * per], info[f * per:(f + 1) * per]) for f in range(16)], 2) * (F / 16)
+out["F2_pose_optimization"] = {"frames": F, "correspondences_per_frame": per, "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms_scaled_from_16": round(t_cpu * 1e3, 1)}
+
+# F3: vocabulary descent of 256 frames' descriptors, k = 10, L = 5 (111 k nodes; ORBvoc is L = 6)
+par, vd, vw = synthetic_tree(10, 5, seed=3, ragged=False)
+voc = ORBVocabulary(10, 5, par, vd, vw, ctx=ctx)
+feats = rng.integers(0, 256, (256 * 1000, 32), dtype=np.uint8)
+t_gpu = timed(lambda: voc.transform_features(feats, 3), 3)
+ref = O.Voc(10, 5, par, vd, vw)
+t_cpu = timed(lambda: ref.transform_features(feats[:20000], 3), 2) * (len(feats) / 20000)
+out["F3_voc_transform"] = {"descriptors": len(feats), "tree_nodes": len(par), "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms_scaled_from_20000": round(t_cpu * 1e3, 1)}
+cnt = rng.integers(3, 30, 20000).astype("i4"); fst = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype("i8")
+dd = rng.integers(0, 256, (int(cnt.sum()), 32), dtype=np.uint8)
+t_gpu = timed(lambda: voc.distinctive_descriptors(dd, fst, cnt), 3)
+t_cpu = timed(lambda: [O.distinctive_descriptor(dd[fst[p]:fst[p] + cnt[p]]) for p in range(1000)], 2) * 20
+out["F3_distinctive_descriptors"] = {"map_points": 20000, "observations": int(cnt.sum()), "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms_scaled_from_1000": round(t_cpu * 1e3, 1)}
+
+# F4: OptimizeSim3, 512 candidate pairs x ~70 correspondences
+probs = [make_problem(rng, int(rng.integers(20, 120)), outlier_frac=0.1) for _ in range(512)]
+sizes = [len(p["info1"]) for p in probs]
+fs = np.concatenate([[0], np.cumsum(sizes)]).astype("i4")
+cat = lambda k: np.concatenate([p[k] for p in probs])
+S0 = np.stack([p["S0"] for p in probs]); K1 = np.stack([p["K1"] for p in probs]); K2 = np.stack([p["K2"] for p in probs])
+args = (cat("P1"), cat("P2"), cat("obs1"), cat("obs2"), cat("info1"), cat("info2"))
+t_gpu = timed(lambda: Optimizer.OptimizeSim3(S0, 0, K1, K2, fs, *args, 10.0, ctx=ctx), 3)
+t_cpu = timed(lambda: [O.optimize_sim3(p["S0"], 0, p["K1"], p["K2"], p["P1"], p["P2"], p["obs1"], p["obs2"], p["info1"], p["info2"], 10.0) for p in probs[:32]], 2) * 16
+out["F4_optimize_sim3"] = {"problems": 512, "correspondences": int(fs[-1]), "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms_scaled_from_32": round(t_cpu * 1e3, 1)}
+print(json.dumps(out))

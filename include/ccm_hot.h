@@ -390,6 +390,30 @@ typedef struct {
 } ccm_sim3_problem;
 int ccm_optimize_sim3(ccm_ctx*, ccm_sim3_problem*);
 
+/* The optimisation inside Optimizer::OptimizeEssentialGraphLoopClosure / OptimizeEssentialGraphMapFusion
+ * (src/Optimizer.cpp:1064-1331, :1333-1574): one VertexSim3Expmap per keyframe (sim3 = Scw or the corrected Sim3,
+ * :1094-1108; fixed = pLoopKF, :1110), one EdgeSim3 per loop / spanning-tree / covisibility edge built by the caller
+ * exactly as :1123-1250 with edge_i = vertex 0, edge_j = vertex 1, measurement = Sji; identity information, numeric
+ * Jacobians, Levenberg with lambda 1e-16, `iterations` = 20.  sim3 comes back as the CorrectedSiw of :1262. */
+typedef struct {
+    int32_t        n_vertices;
+    double*        sim3;          /* [n_vertices][8] in/out: qx,qy,qz,qw, tx,ty,tz, s */
+    const uint8_t* fixed;         /* [n_vertices] */
+    int32_t        fix_scale;     /* bFixScale */
+    int32_t        n_edges;
+    const int32_t* edge_i;        /* [n_edges] */
+    const int32_t* edge_j;
+    const double*  measurement;   /* [n_edges][8] */
+    int32_t        iterations;
+    int32_t        iterations_done;   /* out */
+    double         chi2_initial, chi2_final;   /* out */
+} ccm_essential_graph;
+int ccm_optimize_essential_graph(ccm_ctx*, ccm_essential_graph*);
+/* Map point correction that follows it (:1300-1330): points[i] <- correctedSwr.map(Srw.map(points[i])) with r =
+ * ref_vertex[i] (-1: leave the point), Srw = sim3_before[r] (vScw), correctedSwr = inverse(sim3_after[r]). */
+int ccm_correct_map_points(ccm_ctx*, int n_points, double* points, const int32_t* ref_vertex, int n_vertices, const double* sim3_before,
+                           const double* sim3_after);
+
 /* Multi-GPU GBA: every rank calls ccm_ba_solve with the
  * SAME poses and ITS OWN landmark partition (points + their edges); the reduced
  * camera system is summed with one RCCL all-reduce per LM trial.  One rank

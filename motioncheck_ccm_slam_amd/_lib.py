@@ -30,7 +30,7 @@ SYMBOLS = [
     "ccm_descriptor_distance", "ccm_hamming_match", "ccm_hamming_match_dev", "ccm_ratio_test", "ccm_match_bow",
     "ccm_window_candidates", "ccm_search_by_projection", "ccm_search_by_projection_frame", "ccm_search_for_initialization", "ccm_fuse_select", "ccm_search_by_sim3", "ccm_search_by_projection_sim3",
     "ccm_search_for_triangulation", "ccm_voc_create", "ccm_voc_destroy", "ccm_voc_words", "ccm_voc_transform", "ccm_voc_transform_dev",
-    "ccm_bow_vector", "ccm_bow_score_l1", "ccm_distinctive_descriptors", "ccm_optimize_sim3",
+    "ccm_bow_vector", "ccm_bow_score_l1", "ccm_distinctive_descriptors", "ccm_optimize_sim3", "ccm_optimize_essential_graph", "ccm_correct_map_points",
     "ccm_ba_solve", "ccm_ba_landmark_cuts", "ccm_pose_optimize", "ccm_comm_unique_id", "ccm_comm_init", "ccm_comm_destroy",
     "ccm_pose_from_mat4f", "ccm_pose_to_mat4f",
 ]
@@ -74,6 +74,12 @@ class Sim3Problem(C.Structure):
     _fields_ = [("n_problems", C.c_int), ("sim3", C.c_void_p), ("fix_scale", C.c_void_p), ("K1", C.c_void_p), ("K2", C.c_void_p),
                 ("first", C.c_void_p), ("P1", C.c_void_p), ("P2", C.c_void_p), ("obs1", C.c_void_p), ("obs2", C.c_void_p),
                 ("info1", C.c_void_p), ("info2", C.c_void_p), ("th2", C.c_void_p), ("inlier", C.c_void_p), ("n_inliers", C.c_void_p)]
+
+
+class EssentialGraph(C.Structure):
+    _fields_ = [("n_vertices", C.c_int), ("sim3", C.c_void_p), ("fixed", C.c_void_p), ("fix_scale", C.c_int), ("n_edges", C.c_int),
+                ("edge_i", C.c_void_p), ("edge_j", C.c_void_p), ("measurement", C.c_void_p), ("iterations", C.c_int),
+                ("iterations_done", C.c_int), ("chi2_initial", C.c_double), ("chi2_final", C.c_double)]
 
 
 class BaOptions(C.Structure):
@@ -150,6 +156,8 @@ def load():
     lib.ccm_ba_landmark_cuts.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.ccm_pose_optimize.argtypes = [vp, C.POINTER(PoseProblem)]
     lib.ccm_optimize_sim3.argtypes = [vp, C.POINTER(Sim3Problem)]
+    lib.ccm_optimize_essential_graph.argtypes = [vp, C.POINTER(EssentialGraph)]
+    lib.ccm_correct_map_points.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp]
     lib.ccm_comm_unique_id.argtypes = [vp]
     lib.ccm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.ccm_comm_destroy.argtypes = [vp]

@@ -41,6 +41,7 @@ void ccm_destroy(ccm_ctx* c)
     ba_state_free(c->ba);
     pose_state_free(c->pose);
     sim3_state_free(c->sim3);
+    ess_state_free(c->ess);
     for (ProfLabel& L : c->prof) for (auto& e : L.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -15,6 +15,7 @@ struct BaState;
 struct CommState;
 struct PoseState;
 struct Sim3State;
+struct EssState;
 
 struct ProfLabel { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
 
@@ -30,6 +31,7 @@ struct ccm_ctx {
     CommState* comm = nullptr;
     PoseState* pose = nullptr;
     Sim3State* sim3 = nullptr;
+    EssState* ess = nullptr;
 };
 
 // grow-only device buffer
@@ -91,3 +93,4 @@ void ba_state_free(BaState*);
 void comm_state_free(ccm_ctx*);
 void pose_state_free(PoseState*);
 void sim3_state_free(Sim3State*);
+void ess_state_free(EssState*);

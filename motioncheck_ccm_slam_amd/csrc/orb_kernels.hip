@@ -398,7 +398,7 @@ __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 // v_pk_min_u16): |v - n| <= t  <=>  (u16)(v + t - n) <= 2t.
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
-                                                    unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV)
+                                                    unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
     const OrbBand B = bands[blockIdx.x];
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     const int dw_lo = max(1, c_lo >> 2);
     const int dw_hi = min(PW - 2, (c_hi - 1) >> 2);
     __syncthreads();
+    if (abl == 1) return;                                    // staging only
     for (int r0 = 3; r0 < bh - 3; r0 += RB) {
         if (tid == 0) *nsurv = 0;
         __syncthreads();
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
             }
         }
         __syncthreads();
-        const int ns = min(*nsurv, FC_SURV);
+        const int ns = abl == 2 ? 0 : min(*nsurv, FC_SURV);      // abl 2: no scoring
         for (int si = tid; si < ns; si += 256) {
             const int pos = surv[si];
             const uint8_t* c = T + pos;
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     }
     // ---- NMS on the list of scored pixels.  With minThFAST <= iniThFAST every stored score is >= minThFAST, so
     // "keep at threshold th" == score >= th and strictly greater than every neighbour inside the cell's rectangle.
+    if (abl == 3) return;                                    // no NMS
     const int nnz = nsurv[1];
     const int rh = bh - 6;
     bool listed = g.min_th <= g.ini_th && nnz <= FC_NZ && B.ncells <= FC_CELLS;
@@ -1198,8 +1200,9 @@ void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* c
                            size_t lds_bytes, int surv_cap, unsigned* slots, int* cell_count)
 {
     static const bool packed = !(getenv("CCM_FC_PACKED") && atoi(getenv("CCM_FC_PACKED")) == 0);
-    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap);
-    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap);
+    static const int abl = getenv("CCM_FC_ABL") ? atoi(getenv("CCM_FC_ABL")) : 0;     // timing ablations only (results are wrong)
+    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
+    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
 }
 size_t orb_fast_cells_lds(int pitch, int bh, int surv_cap) { return fc_lds_bytes(pitch, bh, surv_cap); }
 void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,

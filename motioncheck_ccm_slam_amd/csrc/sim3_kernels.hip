@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cfloat>
-#include "ba_math.h"
+#include "sim3_math.h"
 
 #define S3_TPB 256
 
@@ -28,88 +28,6 @@ struct Sim3Dev {
     int* n_in;                // [n] out
 };
 
-__device__ __forceinline__ void s3_quat_mul(const double* a, const double* b, double* o)
-{
-    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ void s3_rotv(const double* q, const double* v, double* o)
-{
-    double R[9]; ba_quat_to_R(q, R);
-    for (int i = 0; i < 3; i++) o[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
-}
-// Sim3(const Vector7d&), sim3.h:62-131
-__device__ void s3_exp(const double* u, double* S)
-{
-    const double* omega = u; const double* upsilon = u + 3;
-    const double sigma = u[6];
-    const double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
-    const double Om[9] = { 0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0 };
-    double Om2[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Om2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
-    const double s = exp(sigma);
-    const double eps = 0.00001;
-    double A, B, C, R[9];
-    if (fabs(sigma) < eps) {
-        C = 1;
-        if (theta < eps) { A = 1. / 2.; B = 1. / 6.; for (int i = 0; i < 9; i++) R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; }
-        else {
-            const double theta2 = theta * theta;
-            A = (1 - cos(theta)) / theta2;
-            B = (theta - sin(theta)) / (theta2 * theta);
-            for (int i = 0; i < 9; i++) R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + sin(theta) / theta * Om[i] + (1 - cos(theta)) / (theta * theta) * Om2[i];
-        }
-    } else {
-        C = (s - 1) / sigma;
-        if (theta < eps) {
-            const double sigma2 = sigma * sigma;
-            A = ((sigma - 1) * s + 1) / sigma2;
-            B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
-            for (int i = 0; i < 9; i++) R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + Om[i] + Om2[i];
-        } else {
-            for (int i = 0; i < 9; i++) R[i] = ((i & 3) == 0 ? 1.0 : 0.0) + sin(theta) / theta * Om[i] + (1 - cos(theta)) / (theta * theta) * Om2[i];
-            const double a = s * sin(theta), b = s * cos(theta);
-            const double theta2 = theta * theta, sigma2 = sigma * sigma;
-            const double c = theta2 + sigma2;
-            A = (a * sigma + (1 - b) * theta) / (theta * c);
-            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
-        }
-    }
-    ba_R_to_quat(R, S);
-    for (int i = 0; i < 3; i++) {
-        S[4 + i] = 0;
-        for (int j = 0; j < 3; j++) S[4 + i] += (A * Om[3 * i + j] + B * Om2[3 * i + j] + C * (i == j ? 1.0 : 0.0)) * upsilon[j];
-    }
-    S[7] = s;
-}
-__device__ void s3_mul(const double* a, const double* b, double* o)      // sim3.h:277-283
-{
-    double q[4], t[3];
-    s3_quat_mul(a, b, q);
-    s3_rotv(a, b + 4, t);
-    for (int i = 0; i < 4; i++) o[i] = q[i];
-    for (int i = 0; i < 3; i++) o[4 + i] = a[7] * t[i] + a[4 + i];
-    o[7] = a[7] * b[7];
-}
-__device__ void s3_inverse(const double* a, double* o)                    // sim3.h:245-248
-{
-    const double qc[4] = { -a[0], -a[1], -a[2], a[3] };
-    const double ts[3] = { (-1. / a[7]) * a[4], (-1. / a[7]) * a[5], (-1. / a[7]) * a[6] };
-    double t[3]; s3_rotv(qc, ts, t);
-    for (int i = 0; i < 4; i++) o[i] = qc[i];
-    for (int i = 0; i < 3; i++) o[4 + i] = t[i];
-    o[7] = 1. / a[7];
-}
-__device__ void s3_oplus(const double* S, const double* upd, int fix_scale, double* o)   // VertexSim3Expmap::oplusImpl
-{
-    double u[7];
-    for (int i = 0; i < 7; i++) u[i] = upd[i];
-    if (fix_scale) u[6] = 0;
-    double E[8]; s3_exp(u, E);
-    s3_mul(E, S, o);
-}
 // projection of x through (R|t|s) given as rotation matrix: e = obs - K(project(s R x + t))
 __device__ __forceinline__ void s3_proj_err(const double* R, const double* t, double s, const double* K, const double* x, const double* obs, double* e)
 {

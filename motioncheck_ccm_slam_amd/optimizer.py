@@ -103,6 +103,30 @@ class Optimizer:
         return s3, inl[:len(A[4])], nin
 
 
+    @staticmethod
+    def OptimizeEssentialGraph(sim3, fixed, edge_i, edge_j, measurement, bFixScale: bool = False, iterations: int = 20, ctx=None):
+        """The pose-graph optimisation of OptimizeEssentialGraphLoopClosure / MapFusion (src/Optimizer.cpp:1064-1574).
+        Returns (corrected Siw per keyframe, dict with iterations_done / chi2_initial / chi2_final)."""
+        ctx = ctx or _lib.default_context(0)
+        lib = _lib.load()
+        a = np.ascontiguousarray
+        s3 = a(sim3, "f8").copy().reshape(-1, 8); fx = a(fixed, np.uint8); ei = a(edge_i, "i4"); ej = a(edge_j, "i4"); ms = a(measurement, "f8")
+        p = _lib.ptr
+        g = _lib.EssentialGraph(len(s3), p(s3), p(fx), int(bFixScale), len(ei), p(ei), p(ej), p(ms), int(iterations), 0, 0.0, 0.0)
+        ctx.check(lib.ccm_optimize_essential_graph(ctx.handle, C.byref(g)))
+        return s3, dict(iterations_done=g.iterations_done, chi2_initial=g.chi2_initial, chi2_final=g.chi2_final)
+
+    @staticmethod
+    def CorrectMapPoints(points, ref_vertex, sim3_before, sim3_after, ctx=None):
+        """P' = correctedSwr.map(Srw.map(P)) per map point (src/Optimizer.cpp:1300-1330)."""
+        ctx = ctx or _lib.default_context(0)
+        a = np.ascontiguousarray
+        pts = a(points, "f8").copy(); rv = a(ref_vertex, "i4"); sb = a(sim3_before, "f8"); sa = a(sim3_after, "f8")
+        p = _lib.ptr
+        ctx.check(_lib.load().ccm_correct_map_points(ctx.handle, len(pts), p(pts), p(rv), len(sb), p(sb), p(sa)))
+        return pts
+
+
 def pose_from_mat4f(T: np.ndarray) -> np.ndarray:
     T = np.ascontiguousarray(T, np.float32); out = np.zeros(7)
     _lib.load().ccm_pose_from_mat4f(_lib.ptr(T), _lib.ptr(out))

@@ -865,3 +865,181 @@ int orc_optimize_sim3(double* sim3, int fix_scale, const double* K1, const doubl
     free(err12); free(err21);
     return nIn;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * F4 (second half): the optimisation inside Optimizer::OptimizeEssentialGraphLoopClosure / MapFusion
+ * (cslam/src/Optimizer.cpp:1064-1331, :1333-1574): VertexSim3Expmap per keyframe, EdgeSim3 (types_seven_dof_expmap.h:
+ * 112-140) with identity information and NUMERIC Jacobians on both vertices, BlockSolver_7_3 + LinearSolverEigen,
+ * Levenberg with setUserLambdaInit(1e-16), optimize(20).  The graph (which edges, their measurements Sji) is built by
+ * the caller exactly as :1123-1250. */
+/* Sim3::log, sim3.h:137-213 */
+void orc_sim3_log(const double* S, double* res)
+{
+    const double s = S[7];
+    const double sigma = log(s);
+    double R[9]; quat_to_R(S, R);
+    const double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+    const double dR[3] = { R[7] - R[5], R[2] - R[6], R[3] - R[1] };
+    double omega[3], A, B, C;
+    const double eps = 0.00001;
+    if (fabs(sigma) < eps) {
+        C = 1;
+        if (d > 1 - eps) { for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i]; A = 1. / 2.; B = 1. / 6.; }
+        else {
+            const double theta = acos(d), theta2 = theta * theta;
+            for (int i = 0; i < 3; i++) omega[i] = theta / (2 * sqrt(1 - d * d)) * dR[i];
+            A = (1 - cos(theta)) / theta2;
+            B = (theta - sin(theta)) / (theta2 * theta);
+        }
+    } else {
+        C = (s - 1) / sigma;
+        if (d > 1 - eps) {
+            const double sigma2 = sigma * sigma;
+            for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i];
+            A = ((sigma - 1) * s + 1) / sigma2;
+            B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
+        } else {
+            const double theta = acos(d);
+            for (int i = 0; i < 3; i++) omega[i] = theta / (2 * sqrt(1 - d * d)) * dR[i];
+            const double theta2 = theta * theta;
+            const double a = s * sin(theta), b = s * cos(theta);
+            const double c = theta2 + sigma * sigma;
+            A = (a * sigma + (1 - b) * theta) / (theta * c);
+            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+        }
+    }
+    const double Om[9] = { 0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0 };
+    double Om2[9]; mat3_mul(Om, Om, Om2);
+    double W[9];
+    for (int i = 0; i < 9; i++) W[i] = A * Om[i] + B * Om2[i] + C * ((i % 4) == 0 ? 1.0 : 0.0);
+    /* upsilon = W.lu().solve(t): Gaussian elimination with partial pivoting */
+    double M[12];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M[4 * i + j] = W[3 * i + j]; M[4 * i + 3] = S[4 + i]; }
+    for (int c = 0; c < 3; c++) {
+        int p = c;
+        for (int r = c + 1; r < 3; r++) if (fabs(M[4 * r + c]) > fabs(M[4 * p + c])) p = r;
+        if (p != c) for (int j = 0; j < 4; j++) { const double t = M[4 * c + j]; M[4 * c + j] = M[4 * p + j]; M[4 * p + j] = t; }
+        for (int r = c + 1; r < 3; r++) {
+            const double f = M[4 * r + c] / M[4 * c + c];
+            for (int j = c; j < 4; j++) M[4 * r + j] -= f * M[4 * c + j];
+        }
+    }
+    double ups[3];
+    for (int r = 2; r >= 0; r--) {
+        double v = M[4 * r + 3];
+        for (int j = r + 1; j < 3; j++) v -= M[4 * r + j] * ups[j];
+        ups[r] = v / M[4 * r + r];
+    }
+    for (int i = 0; i < 3; i++) { res[i] = omega[i]; res[3 + i] = ups[i]; }
+    res[6] = sigma;
+}
+
+/* EdgeSim3::computeError: log(C * Si * Sj^-1), types_seven_dof_expmap.h:119-127 */
+static void ess_error(const double* C, const double* Si, const double* Sj, double* e)
+{
+    double t1[8], inv[8], t2[8];
+    orc_sim3_mul(C, Si, t1);
+    orc_sim3_inverse(Sj, inv);
+    orc_sim3_mul(t1, inv, t2);
+    orc_sim3_log(t2, e);
+}
+
+/* sim3 [n][8] in/out; fixed[n]; edges (ei[k] = vertex 0, ej[k] = vertex 1, meas[k] = Sji).  Dense normal equations
+ * (the reference's sparse Cholesky solves the same system).  Returns the iterations done; chi2 in out[0..1]. */
+int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale, int ne, const int32_t* ei, const int32_t* ej,
+                        const double* meas, int iterations, double* chi2_out)
+{
+    int* fidx = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int nf = 0;
+    for (int i = 0; i < n; i++) fidx[i] = fixed[i] ? -1 : nf++;
+    const int N = 7 * nf;
+    double* H = (double*)calloc((size_t)(N > 0 ? N : 1) * (N > 0 ? N : 1), sizeof(double));
+    double* Hl = (double*)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1) * (N > 0 ? N : 1));
+    double* b = (double*)calloc(N > 0 ? N : 1, sizeof(double));
+    double* x = (double*)calloc(N > 0 ? N : 1, sizeof(double));
+    double* save = (double*)malloc(sizeof(double) * 8 * (size_t)(n > 0 ? n : 1));
+    double lambda = 0, ni = 2;
+    int nBad = 0, done = 0;
+    double first_chi = -1, cur = 0;
+    for (int it = 0; it < iterations && N > 0 && ne > 0; it++) {
+        memset(H, 0, sizeof(double) * (size_t)N * N); memset(b, 0, sizeof(double) * N);
+        cur = 0;
+        for (int k = 0; k < ne; k++) {
+            const double* C = meas + 8 * (size_t)k;
+            double* Si = sim3 + 8 * (size_t)ei[k]; double* Sj = sim3 + 8 * (size_t)ej[k];
+            double e[7]; ess_error(C, Si, Sj, e);
+            for (int r = 0; r < 7; r++) cur += e[r] * e[r];
+            double J[2][49];                                    /* [vertex][row * 7 + d] */
+            for (int v = 0; v < 2; v++) {
+                const int vid = v == 0 ? ei[k] : ej[k];
+                if (fixed[vid]) continue;
+                for (int d = 0; d < 7; d++) {
+                    double up[7] = { 0, 0, 0, 0, 0, 0, 0 }, Sp[8], Sm[8], ea[7], eb[7];
+                    up[d] = 1e-9; sim3_oplus(v == 0 ? Si : Sj, up, fix_scale, Sp);
+                    ess_error(C, v == 0 ? Sp : Si, v == 0 ? Sj : Sp, ea);
+                    up[d] = -1e-9; sim3_oplus(v == 0 ? Si : Sj, up, fix_scale, Sm);
+                    ess_error(C, v == 0 ? Sm : Si, v == 0 ? Sj : Sm, eb);
+                    for (int r = 0; r < 7; r++) J[v][r * 7 + d] = (1.0 / (2 * 1e-9)) * (ea[r] - eb[r]);
+                }
+            }
+            for (int va = 0; va < 2; va++) {
+                const int ia = fidx[va == 0 ? ei[k] : ej[k]];
+                if (ia < 0) continue;
+                for (int p = 0; p < 7; p++) {
+                    double g = 0;
+                    for (int r = 0; r < 7; r++) g += J[va][r * 7 + p] * (-e[r]);
+                    b[7 * ia + p] += g;
+                }
+                for (int vb = 0; vb < 2; vb++) {
+                    const int ib = fidx[vb == 0 ? ei[k] : ej[k]];
+                    if (ib < 0) continue;
+                    for (int p = 0; p < 7; p++) for (int q = 0; q < 7; q++) {
+                        double h = 0;
+                        for (int r = 0; r < 7; r++) h += J[va][r * 7 + p] * J[vb][r * 7 + q];
+                        H[(size_t)(7 * ia + p) * N + 7 * ib + q] += h;
+                    }
+                }
+            }
+        }
+        if (first_chi < 0) first_chi = cur;
+        const double ini = cur;
+        if (it == 0) { lambda = 1e-16; ni = 2; nBad = 0; }      /* setUserLambdaInit(1e-16), :1073 */
+        double rho = 0; int qmax = 0;
+        do {
+            memcpy(save, sim3, sizeof(double) * 8 * (size_t)n);
+            memcpy(Hl, H, sizeof(double) * (size_t)N * N);
+            for (int j = 0; j < N; j++) Hl[(size_t)j * N + j] += lambda;
+            const int ok2 = chol_factor(Hl, N);
+            double temp = DBL_MAX;
+            if (ok2) {
+                memcpy(x, b, sizeof(double) * N); chol_solve(Hl, N, x);
+                for (int v = 0; v < n; v++) {
+                    if (fidx[v] < 0) continue;
+                    double o[8]; sim3_oplus(sim3 + 8 * (size_t)v, x + 7 * fidx[v], fix_scale, o);
+                    memcpy(sim3 + 8 * (size_t)v, o, sizeof o);
+                }
+                temp = 0;
+                for (int k = 0; k < ne; k++) {
+                    double e[7]; ess_error(meas + 8 * (size_t)k, sim3 + 8 * (size_t)ei[k], sim3 + 8 * (size_t)ej[k], e);
+                    for (int r = 0; r < 7; r++) temp += e[r] * e[r];
+                }
+            } else memset(x, 0, sizeof(double) * N);
+            double scale = 1e-3;
+            for (int j = 0; j < N; j++) scale += x[j] * (lambda * x[j] + b[j]);
+            rho = ok2 ? (cur - temp) / scale : -1.0;
+            if (rho > 0 && isfinite(temp)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2; cur = temp;
+            } else { lambda *= ni; ni *= 2; memcpy(sim3, save, sizeof(double) * 8 * (size_t)n); }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        done = it + 1;
+        if (qmax == 10 || rho == 0) break;
+        if ((ini - cur) * 1e3 < ini) nBad++; else nBad = 0;
+        if (nBad >= 3) break;
+    }
+    if (chi2_out) { chi2_out[0] = first_chi < 0 ? 0 : first_chi; chi2_out[1] = cur; }
+    free(fidx); free(H); free(Hl); free(b); free(x); free(save);
+    return done;
+}

@@ -143,6 +143,9 @@ int  orc_ba_reduced_system(const orc_ba_problem*, double huber_delta, double lam
 void orc_sim3_exp(const double* update7, double* sim3);
 void orc_sim3_mul(const double* a, const double* b, double* o);
 void orc_sim3_inverse(const double* a, double* o);
+void orc_sim3_log(const double* sim3, double* log7);
+int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale, int ne, const int32_t* ei, const int32_t* ej,
+                        const double* meas, int iterations, double* chi2_out);
 int orc_optimize_sim3(double* sim3, int fix_scale, const double* K1, const double* K2, int n, const double* P1, const double* P2,
                       const double* obs1, const double* obs2, const double* info1, const double* info2, float th2, uint8_t* inlier);
 #endif

@@ -368,3 +368,16 @@ def sim3_inverse(a):
     a = np.ascontiguousarray(a, "f8"); o = np.zeros(8)
     lib().orc_sim3_inverse(_p(a), _p(o))
     return o
+
+
+def sim3_log(s):
+    s = np.ascontiguousarray(s, "f8"); o = np.zeros(7)
+    lib().orc_sim3_log(_p(s), _p(o))
+    return o
+
+
+def essential_graph(sim3, fixed, edge_i, edge_j, meas, fix_scale=False, iterations=20):
+    a = lambda x, t: np.ascontiguousarray(x, t)
+    s = a(sim3, "f8").copy(); fx = a(fixed, np.uint8); ei = a(edge_i, "i4"); ej = a(edge_j, "i4"); ms = a(meas, "f8"); chi = np.zeros(2)
+    done = lib().orc_essential_graph(len(s), _p(s), _p(fx), int(fix_scale), len(ei), _p(ei), _p(ej), _p(ms), int(iterations), _p(chi))
+    return s, dict(iterations_done=done, chi2_initial=chi[0], chi2_final=chi[1])

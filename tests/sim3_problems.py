@@ -37,3 +37,39 @@ def make_problem(rng, n, outlier_frac=0.1, noise=0.5, start_err=0.05):
     S0[:4] += rng.normal(0, start_err * 0.3, 4); S0[:4] /= np.linalg.norm(S0[:4])
     S0[4:7] += rng.normal(0, start_err, 3); S0[7] *= np.exp(rng.normal(0, start_err))
     return dict(S_true=S_true, S0=S0, K1=K1, K2=K2, P1=P1, P2=P2, obs1=obs1, obs2=obs2, info1=info1, info2=info2, bad=bad)
+
+
+def make_pose_graph(oracle, rng, n=60, drift=0.01, scale_drift=0.004, covis=2):
+    """A closed trajectory of n keyframes with accumulated Sim3 drift, as the loop closer sees it: vertex estimates are
+    the drifted Siw except the current keyframe (last), which carries its loop-corrected Sim3; spanning-tree and
+    covisibility edges are measured from the drifted estimates (NonCorrectedSim3), the loop edge from the truth.
+    Returns sim3 [n][8], fixed, edge_i, edge_j, meas [ne][8], truth [n][8]."""
+    truth = []
+    for i in range(n):
+        ang = 2 * np.pi * i / n
+        c = np.array([3 * np.cos(ang), 0.2 * np.sin(3 * ang), 3 * np.sin(ang)])
+        yaw = -ang
+        q = np.array([0, np.sin(yaw / 2), 0, np.cos(yaw / 2)])
+        t = -quat_R(q) @ c
+        truth.append(np.concatenate([q, t, [1.0]]))
+    truth = np.array(truth)
+    drifted = [truth[0].copy()]
+    for i in range(1, n):
+        rel = oracle.sim3_mul(truth[i], oracle.sim3_inverse(truth[i - 1]))                      # S_i,i-1
+        noise = oracle.sim3_exp(np.concatenate([rng.normal(0, drift, 3), rng.normal(0, drift, 3), [rng.normal(0, scale_drift)]]))
+        drifted.append(oracle.sim3_mul(oracle.sim3_mul(noise, rel), drifted[i - 1]))
+    drifted = np.array(drifted)
+    ei, ej, meas = [], [], []
+
+    def edge(i, j, Si, Sj):                                                                   # vertex 0 = i, vertex 1 = j, Sji = Sjw * Swi
+        ei.append(i); ej.append(j); meas.append(oracle.sim3_mul(Sj, oracle.sim3_inverse(Si)))
+    for i in range(1, n):
+        edge(i, i - 1, drifted[i], drifted[i - 1])                                             # spanning tree
+        for k in range(2, covis + 2):
+            if i - k >= 0:
+                edge(i, i - k, drifted[i], drifted[i - k])                                     # covisibility, nIDj < nIDi
+    edge(n - 1, 0, truth[n - 1], truth[0])                                                     # the loop connection
+    sim3 = drifted.copy()
+    sim3[n - 1] = truth[n - 1]                                                                 # CorrectedSim3 of the current keyframe
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    return sim3, fixed, np.array(ei, "i4"), np.array(ej, "i4"), np.array(meas), truth

@@ -53,3 +53,40 @@ def test_optimize_sim3_many_candidates(ctx, oracle):
         rS, rinl, rn = oracle.optimize_sim3(p["S0"], 0, p["K1"], p["K2"], p["P1"], p["P2"], p["obs1"], p["obs2"], p["info1"], p["info2"], 10.0)
         assert nin[i] == rn and (inl[first[i]:first[i + 1]] == rinl).all() and np.abs(S[i] - rS).max() < 1e-7
     assert (nin > 10).mean() > 0.95
+
+
+@pytest.mark.parametrize("n,fix_scale", [(40, False), (120, False), (60, True)])
+def test_essential_graph_matches_oracle(ctx, oracle, n, fix_scale):
+    from sim3_problems import make_pose_graph
+    rng = np.random.default_rng(100 + n)
+    sim3, fixed, ei, ej, meas, truth = make_pose_graph(oracle, rng, n=n)
+    out, info = Optimizer.OptimizeEssentialGraph(sim3, fixed, ei, ej, meas, fix_scale, 20, ctx=ctx)
+    ref, rinfo = oracle.essential_graph(sim3, fixed, ei, ej, meas, fix_scale, 20)
+    assert info["iterations_done"] == rinfo["iterations_done"]
+    assert np.isclose(info["chi2_initial"], rinfo["chi2_initial"], rtol=1e-9) and np.isclose(info["chi2_final"], rinfo["chi2_final"], rtol=1e-6)
+    # tolerance: the contract's 1e-5 on pose updates; numeric Jacobians (delta 1e-9) on both sides
+    assert np.abs(out - ref).max() < 1e-6, np.abs(out - ref).max()
+    assert (out[0] == sim3[0]).all() and info["chi2_final"] < 0.05 * info["chi2_initial"]
+    if fix_scale:
+        assert np.allclose(out[:, 7], sim3[:, 7], rtol=0, atol=0)
+    # map point correction: points attached to reference keyframes follow them
+    pts = rng.normal(0, 3, (500, 3)); refv = rng.integers(-1, n, 500)
+    moved = Optimizer.CorrectMapPoints(pts, refv, sim3, out, ctx=ctx)
+    for i in (0, 7, 123, 499):
+        r = refv[i]
+        if r < 0:
+            assert (moved[i] == pts[i]).all(); continue
+        exp = sim3_map(oracle.sim3_inverse(out[r]), sim3_map(sim3[r], pts[i][None]))[0]
+        assert np.abs(moved[i] - exp).max() < 1e-12
+
+
+def test_essential_graph_2000_keyframes_properties(ctx, oracle):
+    """BASELINE's map size (2000 keyframes): too slow for the dense CPU oracle, so size-independent properties: the
+    error drops, the fixed keyframe stays, the loop keyframe pair agrees with the loop measurement afterwards."""
+    from sim3_problems import make_pose_graph
+    rng = np.random.default_rng(9)
+    sim3, fixed, ei, ej, meas, truth = make_pose_graph(oracle, rng, n=2000, drift=0.002, scale_drift=0.0005, covis=3)
+    out, info = Optimizer.OptimizeEssentialGraph(sim3, fixed, ei, ej, meas, False, 20, ctx=ctx)
+    assert info["chi2_final"] < 0.05 * info["chi2_initial"] and (out[0] == sim3[0]).all()
+    loop_err = oracle.sim3_log(oracle.sim3_mul(oracle.sim3_mul(meas[-1], out[ei[-1]]), oracle.sim3_inverse(out[ej[-1]])))
+    assert np.abs(loop_err).max() < 0.05

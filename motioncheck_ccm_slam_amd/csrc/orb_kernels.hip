@@ -77,33 +77,47 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom g, int level)
         b0[r] = bb & 0xFFFFu; b1[r] = bb >> 16;
     }
     if (x4 >= D.w) return;
-    if (x4 + 3 < D.w) {
-        // tables of the 4 outputs in two 16-byte loads
-        int4 so; uint4 ab;                                   // tables are only 4-/2-byte aligned
-        __builtin_memcpy(&so, D.xofs + x4, 16);
-        __builtin_memcpy(&ab, D.xab + 2 * x4, 16);
-        const int sxs[4] = { so.x, so.y, so.z, so.w };
-        const unsigned abw[4] = { ab.x, ab.y, ab.z, ab.w };
-        const int base = so.x;
-        const unsigned ba = (unsigned)(base & ~3);
-        if (so.w + 1 - base < 8 && base + 8 <= S.w && (int)ba + 12 <= S.pitch) {
-            // the 4 outputs read source columns base .. base+7 at most: three aligned dwords per source row,
-            // shifted into place by v_alignbyte
+    {
+        // tables of the 4 outputs: two 16-byte loads (the tables are only 4-/2-byte aligned); the last, partial quad of
+        // a row repeats its last column (the bytes past D.w land in the row padding, which nothing reads as data)
+        int sxs[4]; unsigned abw[4];
+        if (x4 + 3 < D.w) {
+            int4 so; uint4 ab;
+            __builtin_memcpy(&so, D.xofs + x4, 16);
+            __builtin_memcpy(&ab, D.xab + 2 * x4, 16);
+            sxs[0] = so.x; sxs[1] = so.y; sxs[2] = so.z; sxs[3] = so.w;
+            abw[0] = ab.x; abw[1] = ab.y; abw[2] = ab.z; abw[3] = ab.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = min(x4 + i, D.w - 1);
+                sxs[i] = D.xofs[x];
+                __builtin_memcpy(&abw[i], D.xab + 2 * x, 4);
+            }
+        }
+        // The 4 outputs read source columns base .. base+7 at most.  At the right border the 8-byte window is pulled
+        // back inside the row (the neighbour weight of the last column is 0, so its clamped byte is never used), and
+        // the 12-byte fetch is pulled back inside the pitch: every lane takes this path, no divergent border code.
+        const int base = min(sxs[0], S.w - 8);
+        const int ba = min(base & ~3, S.pitch - 12);
+        if (S.w >= 8 && S.pitch >= 12 && sxs[3] - base <= 7) {
             uint2 q0[RS_ROWS], q1[RS_ROWS];
-            const unsigned sh = (unsigned)(base & 3);
+            const unsigned sh = (unsigned)(base - ba);            // 0..4
+            const bool sh4 = sh > 3u;
 #pragma unroll
             for (int r = 0; r < RS_ROWS; r++) {
-                const unsigned* p0 = reinterpret_cast<const unsigned*>(r0p[r] + ba);
-                const unsigned* p1 = reinterpret_cast<const unsigned*>(r1p[r] + ba);
+                const unsigned* p0 = reinterpret_cast<const unsigned*>(r0p[r] + (unsigned)ba);
+                const unsigned* p1 = reinterpret_cast<const unsigned*>(r1p[r] + (unsigned)ba);
                 const unsigned d00 = p0[0], d01 = p0[1], d02 = p0[2], d10 = p1[0], d11 = p1[1], d12 = p1[2];
-                q0[r].x = __builtin_amdgcn_alignbyte(d01, d00, sh); q0[r].y = __builtin_amdgcn_alignbyte(d02, d01, sh);
-                q1[r].x = __builtin_amdgcn_alignbyte(d11, d10, sh); q1[r].y = __builtin_amdgcn_alignbyte(d12, d11, sh);
+                const unsigned l0 = sh4 ? d01 : d00, m0 = sh4 ? d02 : d01, l1 = sh4 ? d11 : d10, m1 = sh4 ? d12 : d11;
+                q0[r].x = __builtin_amdgcn_alignbyte(m0, l0, sh); q0[r].y = __builtin_amdgcn_alignbyte(d02, m0, sh);   // v_alignbyte uses sh & 3
+                q1[r].x = __builtin_amdgcn_alignbyte(m1, l1, sh); q1[r].y = __builtin_amdgcn_alignbyte(d12, m1, sh);
             }
             unsigned sel[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const unsigned o = (unsigned)(sxs[i] - base);
-                sel[i] = 0x0c010c00u + o + (o << 16);       // v_perm_b32: bytes o and o+1 as a u16 pair
+                sel[i] = 0x0c000c00u + o + (min(o + 1u, 7u) << 16);   // v_perm_b32: bytes o and o+1 as a u16 pair
             }
 #pragma unroll
             for (int r = 0; r < RS_ROWS; r++) {

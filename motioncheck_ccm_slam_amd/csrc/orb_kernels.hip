@@ -47,7 +47,7 @@ __device__ __forceinline__ int wave_sum(int v)
 // Fixed-point bilinear exactly as cv::resize(INTER_LINEAR) for 8-bit data:
 // weights are the host-made 11-bit tables, horizontal pass int32, vertical pass
 // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.
-#define RS_ROWS 4
+#define RS_ROWS 8
 __global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom g, int level)
 {
     const OrbLevel& D = g.lv[level];

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 #define FC_CELLS 32
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {
-    return 2 * (size_t)pitch * bh + (size_t)surv_cap * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 12;
+    return 2 * (size_t)pitch * bh + (size_t)surv_cap * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 12 + 64;
 }
 
 
@@ -429,6 +429,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     int* cell_n = cell_hi + FC_CELLS;                        // per cell: keypoints written
     short* clo = reinterpret_cast<short*>(cell_n + FC_CELLS); // per cell: first detection column of the tile, and its width
     short* cwd = clo + FC_CELLS;
+    uint8_t* colmask = reinterpret_cast<uint8_t*>(cwd + FC_CELLS);   // per tile dword: which of its 4 pixels are detection columns
     if (tid < FC_CELLS) {
         cell_hi[tid] = 0; cell_n[tid] = 0;
         if (tid < B.ncells) {
@@ -466,6 +467,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     // dwords that hold at least one detection column and have both neighbours inside the row
     const int dw_lo = max(1, c_lo >> 2);
     const int dw_hi = min(PW - 2, (c_hi - 1) >> 2);
+    if (tid < PW) {
+        unsigned mk = 0;
+        for (int i = 0; i < 4; i++) if (4 * tid + i >= c_lo && 4 * tid + i < c_hi) mk |= 1u << i;
+        colmask[tid] = (uint8_t)mk;
+    }
     __syncthreads();
     if (abl == 1) return;                                    // staging only
     for (int r0 = 3; r0 < bh - 3; r0 += RB) {
@@ -518,14 +524,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
                     const fc_us2 dm = __builtin_elementwise_max(__builtin_elementwise_min(n, sq), __builtin_elementwise_min(e, w));
                     kk[h] = fc_u(__builtin_elementwise_sub_sat(bm, (fc_us2)(v + tt))) | fc_u(__builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, tt), dm));
                 }
-                if ((kk[0] | kk[1]) != 0u) {
-                    keep4 = ((kk[0] & 0xFFFFu) ? 1u : 0u) | ((kk[1] & 0xFFFFu) ? 2u : 0u) | ((kk[0] >> 16) ? 4u : 0u) | ((kk[1] >> 16) ? 8u : 0u);
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (px + i < c_lo || px + i >= c_hi) keep4 &= ~(1u << i);
-                }
+                // halves -> 0/1 (v_pk_min_u16), then bits 0..3 = pixels 0..3, masked by the dword's detection columns
+                const unsigned z0 = fc_u(__builtin_elementwise_min(fc_pk(kk[0]), fc_pk(0x00010001u)));
+                const unsigned z1 = fc_u(__builtin_elementwise_min(fc_pk(kk[1]), fc_pk(0x00010001u)));
+                const unsigned zz = z0 | (z1 << 1);
+                keep4 = ((zz & 3u) | ((zz >> 14) & 12u)) & colmask[dw];
             }
-            if (__ballot(keep4 != 0u) != 0ull) {               // one LDS atomic per wave and item
+            if (__ballot(keep4 != 0u) != 0ull) {               // one LDS atomic per wave and item (a per-lane atomic on the one counter measured slower)
                 const unsigned long long m0 = __ballot((keep4 & 1u) != 0u), m1 = __ballot((keep4 & 2u) != 0u);
                 const unsigned long long m2 = __ballot((keep4 & 4u) != 0u), m3 = __ballot((keep4 & 8u) != 0u);
                 const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);

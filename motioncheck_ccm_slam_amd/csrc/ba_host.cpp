@@ -49,7 +49,8 @@ void sp_launch_schur_blocks(hipStream_t, const BaDev&, const double* Y, const un
 void sp_launch_bschur(hipStream_t, const BaDev&, const double* db, double* bs);
 void sp_launch_add_lambda(hipStream_t, const int* diag, int nfree, double lambda, double* Hb);
 void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs);
-void pcg_launch_minv(hipStream_t, const double* Hb, const int* diag, int nfree, double* Minv, int* bad);
+size_t pcg_minv_bytes(int nfree);
+hipError_t pcg_launch_minv(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int nfree, double* Minv, int* bad);
 void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc);
 void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
                      int nfree, double* w, double* pap_part, double* part, double* sc, int first, int parity);
@@ -315,7 +316,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         CCM_HIP(c, hipMemsetAsync(S.row_ptr.p, 0, (size_t)nfree * 8, st));
         sp_launch_row_ptr(st, S.ent_key2.as<unsigned>(), 2 * nb, nfree, S.row_ptr.as<int>());
         CCM_RESERVE(c, S.Hb, (36 * (size_t)nb + (size_t)n + 8) * 8);          // blocks, then bschur: one all-reduce covers both
-        CCM_RESERVE(c, S.Minv, 36 * (size_t)nfree * 8); CCM_RESERVE(c, S.pcg_w, 5 * (size_t)n * 8 + 64);
+        CCM_RESERVE(c, S.Minv, pcg_minv_bytes(nfree)); CCM_RESERVE(c, S.pcg_w, 5 * (size_t)n * 8 + 64);
         CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)n / 192 + 4) * 3 * 8 + 64);
         CCM_RESERVE(c, S.pcg_sc, 64 * 8);
         CCM_HIP(c, hipGetLastError());
@@ -423,7 +424,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     if (use_pcg) {
                         int* bad = info_dev + 1;
                         CCM_HIP(c, hipMemsetAsync(bad, 0, 4, st));
-                        pcg_launch_minv(st, Hb, S.diag_id.as<int>(), nfree, S.Minv.as<double>(), bad);
+                        CCM_HIP(c, pcg_launch_minv(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, nfree, S.Minv.as<double>(), bad));
                         pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>());
                         const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
                         static const double env_tol = getenv("CCM_PCG_TOL") ? atof(getenv("CCM_PCG_TOL")) : 0.0;

@@ -230,60 +230,90 @@ __global__ __launch_bounds__(256) void k_sp_to_dense(const double* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------- PCG
-// Minv = inverse of each diagonal block by Gauss-Jordan on the SPD block (no pivoting); flags non-positive pivots
-__global__ __launch_bounds__(64) void k_pcg_minv(const double* __restrict__ Hb, const int* __restrict__ diag_id, int nfree,
-                                                 double* __restrict__ Minv, int* __restrict__ bad)
+// Cluster-Jacobi preconditioner: M = the diagonal blocks of PCG_CL consecutive free keyframes INCLUDING the coupling
+// blocks between them (consecutive keyframes of a trajectory share most of their landmarks, so these are the strongest
+// off-diagonal blocks of the reduced camera system); its inverse is a dense PCG_CN x PCG_CN matrix per cluster, applied
+// as a mat-vec.  Minv layout: [cluster][PCG_CN][PCG_CN], symmetric.
+#define PCG_CL 8
+#define PCG_CN (6 * PCG_CL)
+__global__ __launch_bounds__(256) void k_pcg_cl_gather(const double* __restrict__ Hb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                       int nb, double* __restrict__ Mc)
 {
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= nfree) return;
-    double a[36], inv[36];
-    const double* src = Hb + 36 * (long long)diag_id[f];
-    for (int i = 0; i < 36; i++) { a[i] = src[i]; inv[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= 36LL * nb) return;
+    const int b = (int)(i / 36), e = (int)(i - 36LL * b), r = e / 6, c = e - 6 * r;
+    const int br = blk_row[b], bc = blk_col[b];
+    if (br / PCG_CL != bc / PCG_CL) return;
+    double* M = Mc + (long long)(br / PCG_CL) * PCG_CN * PCG_CN;
+    const int rr = 6 * (br % PCG_CL) + r, cc = 6 * (bc % PCG_CL) + c;
+    const double v = Hb[i];
+    M[rr * PCG_CN + cc] = v;
+    M[cc * PCG_CN + rr] = v;            // upper block triangle stored once; a diagonal block writes its own mirror
+}
+// in-place inverse of every cluster matrix by Gauss-Jordan without pivoting (SPD); unused rows of the last cluster
+// are made identity; a non-positive pivot raises `bad`
+__global__ __launch_bounds__(64) void k_pcg_cl_invert(double* __restrict__ Mc, int nfree, int* __restrict__ bad)
+{
+    __shared__ double a[PCG_CN][PCG_CN + 1], inv[PCG_CN][PCG_CN + 1];
+    __shared__ double fcol[PCG_CN];
+    double* M = Mc + (long long)blockIdx.x * PCG_CN * PCG_CN;
+    const int used = 6 * min(PCG_CL, nfree - (int)blockIdx.x * PCG_CL);
+    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 64) {
+        const int r = i / PCG_CN, c = i - r * PCG_CN;
+        a[r][c] = (r < used && c < used) ? M[i] : (r == c ? 1.0 : 0.0);
+        inv[r][c] = r == c ? 1.0 : 0.0;
+    }
+    __syncthreads();
     bool ok = true;
-    for (int k = 0; k < 6; k++) {
-        const double piv = a[k * 6 + k];
+    for (int k = 0; k < PCG_CN; k++) {
+        const double piv = a[k][k];
         if (!(piv > 0.0)) ok = false;
         const double ip = 1.0 / piv;
-        for (int j = 0; j < 6; j++) { a[k * 6 + j] *= ip; inv[k * 6 + j] *= ip; }
-        for (int i = 0; i < 6; i++) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < 2 * PCG_CN; j += 64) { if (j < PCG_CN) a[k][j] *= ip; else inv[k][j - PCG_CN] *= ip; }
+        if (threadIdx.x < PCG_CN) fcol[threadIdx.x] = a[threadIdx.x][k];
+        __syncthreads();
+        for (int e = threadIdx.x; e < PCG_CN * 2 * PCG_CN; e += 64) {
+            const int i = e / (2 * PCG_CN), j = e - i * 2 * PCG_CN;
             if (i == k) continue;
-            const double fct = a[i * 6 + k];
-            for (int j = 0; j < 6; j++) { a[i * 6 + j] -= fct * a[k * 6 + j]; inv[i * 6 + j] -= fct * inv[k * 6 + j]; }
+            if (j < PCG_CN) a[i][j] -= fcol[i] * a[k][j]; else inv[i][j - PCG_CN] -= fcol[i] * inv[k][j - PCG_CN];
         }
+        __syncthreads();
     }
-    for (int i = 0; i < 36; i++) Minv[36 * (long long)f + i] = inv[i];
-    if (!ok) atomicOr(bad, 1);
+    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 64) M[i] = inv[i / PCG_CN][i % PCG_CN];
+    if (!ok && threadIdx.x == 0) atomicOr(bad, 1);
 }
 
 // state vector layout in `w`: x | r | z | p | Ap  (each n doubles); scalars in sc[]:
 //   sc[0] rz, sc[1] |b|^2, sc[2] |r|^2, sc[3] min p.Ap seen, sc[4] iterations
-__global__ __launch_bounds__(256) void k_pcg_init(const double* __restrict__ b, const double* __restrict__ Minv, int nfree,
-                                                  double* __restrict__ w, double* __restrict__ part)
+#define PCG_UPD_TPB 192       // 4 clusters of PCG_CN scalars: a cluster never straddles two blocks
+static_assert(PCG_UPD_TPB % PCG_CN == 0, "a block must hold whole clusters");
+__global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restrict__ b, const double* __restrict__ Minv, int nfree,
+                                                          double* __restrict__ w, double* __restrict__ part)
 {
-    __shared__ double red[2][4];
-    const int f = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double rs[PCG_UPD_TPB];
+    __shared__ double red[2][3];
     const long long n = 6LL * nfree;
+    const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
+    const double ri = o < n ? b[o] : 0.0;
+    rs[threadIdx.x] = ri;
+    __syncthreads();
     double rz = 0, bb = 0;
-    if (f < nfree) {
-        double r[6], z[6];
-        for (int i = 0; i < 6; i++) r[i] = b[6 * (long long)f + i];
-        for (int i = 0; i < 6; i++) {
-            double s = 0;
-            for (int j = 0; j < 6; j++) s += Minv[36 * (long long)f + i * 6 + j] * r[j];
-            z[i] = s;
-        }
-        for (int i = 0; i < 6; i++) {
-            const long long o = 6LL * f + i;
-            w[o] = 0.0; w[n + o] = r[i]; w[2 * n + o] = z[i]; w[3 * n + o] = z[i];
-            rz += r[i] * z[i]; bb += r[i] * r[i];
-        }
+    if (o < n) {
+        const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
+        const double* M = Minv + (long long)cl * PCG_CN * PCG_CN + li;
+        double z = 0;
+#pragma unroll 8
+        for (int k = 0; k < PCG_CN; k++) z += M[k * PCG_CN] * rs[base + k];       // symmetric: column li read with unit stride across lanes
+        w[o] = 0.0; w[n + o] = ri; w[2 * n + o] = z; w[3 * n + o] = z;
+        rz = ri * z; bb = ri * ri;
     }
     for (int s = 32; s >= 1; s >>= 1) { rz += __shfl_xor(rz, s, 64); bb += __shfl_xor(bb, s, 64); }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = rz; red[1][threadIdx.x >> 6] = bb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + red[0][2];
+        part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + red[1][2];
     }
 }
 __global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ part, int nblk, double* __restrict__ sc)
@@ -361,23 +391,20 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
     }
 }
 
-// x += alpha p; r -= alpha Ap; z = Minv r; partial r.z and r.r.  One thread per scalar unknown (the six new
-// residual components of its pose are recomputed locally).  Every block re-reduces p.Ap (nfree values) itself.
-#define PCG_UPD_TPB 192       // a multiple of 6: the six scalars of a pose never straddle two blocks
+// x += alpha p; r -= alpha Ap; z = Minv r (cluster mat-vec); partial r.z and r.r.  One thread per scalar unknown, a
+// block holds 4 whole clusters whose new residuals are shared through LDS.  Every block re-reduces p.Ap itself.
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __restrict__ Minv, int nfree, double* __restrict__ w,
                                                             const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part,
                                                             int parity)
 {
-    __shared__ double red[256];
+    __shared__ double red[4];
     __shared__ double red2[2][3];
+    __shared__ double rs[PCG_UPD_TPB];
     const long long n = 6LL * nfree;
     const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
     // everything this thread needs is requested before the reduction, so that all global loads overlap
-    double r_old[6], ap[6], mi[6], x_old = 0, p_old = 0;
-    const long long f = o < n ? o / 6 : 0; const int i = (int)(o < n ? o - 6 * f : 0);
-#pragma unroll
-    for (int j = 0; j < 6; j++) { r_old[j] = w[n + 6 * f + j]; ap[j] = w[4 * n + 6 * f + j]; mi[j] = Minv[36 * f + i * 6 + j]; }
-    if (o < n) { x_old = w[o]; p_old = w[3 * n + o]; }
+    double r_old = 0, ap = 0, x_old = 0, p_old = 0;
+    if (o < n) { r_old = w[n + o]; ap = w[4 * n + o]; x_old = w[o]; p_old = w[3 * n + o]; }
     const double rz_old = sc[8 + parity];
     double s = 0;
 #pragma unroll 4
@@ -387,19 +414,19 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     __syncthreads();
     const double pap = (red[0] + red[1]) + red[2];
     const double alpha = pap > 0.0 ? rz_old / pap : 0.0;
-    double rz = 0, rr = 0, xi = 0, ri = 0, z = 0;
+    const double ri = r_old - alpha * ap;
+    rs[threadIdx.x] = ri;
+    __syncthreads();
+    double rz = 0, rr = 0;
     if (o < n) {
-        double rn[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) rn[j] = r_old[j] - alpha * ap[j];
-#pragma unroll
-        for (int j = 0; j < 6; j++) z += mi[j] * rn[j];
-        xi = x_old + alpha * p_old;
-        ri = rn[i];
+        const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
+        const double* M = Minv + (long long)cl * PCG_CN * PCG_CN + li;
+        double z = 0;
+#pragma unroll 8
+        for (int k = 0; k < PCG_CN; k++) z += M[k * PCG_CN] * rs[base + k];
+        w[o] = x_old + alpha * p_old; w[n + o] = ri; w[2 * n + o] = z;
         rz = ri * z; rr = ri * ri;
     }
-    __syncthreads();                          // every thread of the block has read the old residual of its pose
-    if (o < n) { w[o] = xi; w[n + o] = ri; w[2 * n + o] = z; }
     for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); }
     if ((threadIdx.x & 63) == 0) { red2[0][threadIdx.x >> 6] = rz; red2[1][threadIdx.x >> 6] = rr; }
     __syncthreads();
@@ -504,12 +531,20 @@ void sp_launch_add_lambda(hipStream_t s, const int* diag, int nfree, double lamb
 { hipLaunchKernelGGL(k_sp_add_lambda, dim3(nblk(6LL * nfree, 256)), dim3(256), 0, s, diag, nfree, lambda, Hb); }
 void sp_launch_to_dense(hipStream_t s, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs)
 { hipLaunchKernelGGL(k_sp_to_dense, dim3(nblk(36LL * nb, 256)), dim3(256), 0, s, Hb, br, bc, nb, n, Hs); }
-void pcg_launch_minv(hipStream_t s, const double* Hb, const int* diag, int nfree, double* Minv, int* bad)
-{ hipLaunchKernelGGL(k_pcg_minv, dim3(nblk(nfree, 64)), dim3(64), 0, s, Hb, diag, nfree, Minv, bad); }
+size_t pcg_minv_bytes(int nfree) { return (size_t)nblk(nfree, PCG_CL) * PCG_CN * PCG_CN * 8; }
+hipError_t pcg_launch_minv(hipStream_t s, const double* Hb, const int* blk_row, const int* blk_col, int nb, int nfree, double* Minv, int* bad)
+{
+    const int ncl = nblk(nfree, PCG_CL);
+    hipError_t e = hipMemsetAsync(Minv, 0, pcg_minv_bytes(nfree), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pcg_cl_gather, dim3(nblk(36LL * nb, 256)), dim3(256), 0, s, Hb, blk_row, blk_col, nb, Minv);
+    hipLaunchKernelGGL(k_pcg_cl_invert, dim3(ncl), dim3(64), 0, s, Minv, nfree, bad);
+    return hipSuccess;
+}
 void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc)
 {
-    const int nb = nblk(nfree, 256);
-    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(256), 0, s, b, Minv, nfree, w, part);
+    const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
+    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part);
     hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, sc);
 }
 // `first` = this is the first iteration since pcg_launch_init or pcg_launch_publish (nothing pending to publish)

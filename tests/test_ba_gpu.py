@@ -89,3 +89,34 @@ def test_full_gba_properties(ctx):
     assert pose_delta(again["poses"], r3["poses"]).max() < 1e-8
     e0 = pose_delta(g["poses"], g["gt_poses"]); e1 = pose_delta(r6["poses"], g["gt_poses"])
     assert np.median(e1) < 0.25 * np.median(e0)
+
+
+def test_iterative_solver_forced_on_small_graphs():
+    """The reduced-camera PCG (cluster-Jacobi, HIP graph) normally starts above 256 free keyframes, where the oracle's
+    dense solve is too slow to compare with.  A child process with CCM_BA_DENSE_MAX=0 runs the oracle-sized graphs
+    through it: odd cluster sizes (13, 60 and 239 free keyframes), robust and two-stage schedules."""
+    import subprocess, sys
+    code = r'''
+import numpy as np
+from motioncheck_ccm_slam_amd import _lib, synth
+from motioncheck_ccm_slam_amd.optimizer import Optimizer, pose_delta
+from oracle import oracle_py as O
+ctx = _lib.Context(0)
+g = synth.local_ba_graph()
+r = Optimizer.LocalBundleAdjustmentClient(g, ctx=ctx); ref = O.ba_solve(g, 5, float(np.sqrt(5.991)), 10)
+assert r["pcg_iterations"] > 0, "the dense path ran"
+assert pose_delta(r["poses"], ref["poses"]).max() <= 1e-5 and (r["outlier"] == ref["outlier"]).all()
+assert r["iterations_done"] == ref["iterations_done"] and r["trials"] == ref["trials"]
+for kf, pts, its in ((60, 3000, 8), (240, 20000, 4)):
+    g = synth.gba_graph(n_kf=kf, n_points=pts, n_agents=3, seed=kf)
+    r = Optimizer.MapFusionGBA(g, its, ctx=ctx); ref = O.ba_solve(g, its, float(np.sqrt(5.99)))
+    assert r["pcg_iterations"] > 0 and r["pcg_fallbacks"] == 0
+    d = pose_delta(r["poses"], ref["poses"]).max()
+    assert d <= 1e-5 and r["iterations_done"] == ref["iterations_done"], (kf, d)
+    strict = Optimizer.MapFusionGBA(g, its, ctx=ctx, pcg_tol=1e-13)
+    assert pose_delta(strict["poses"], ref["poses"]).max() <= 1e-9
+print("ok")
+'''
+    env = dict(os.environ, CCM_BA_DENSE_MAX="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]

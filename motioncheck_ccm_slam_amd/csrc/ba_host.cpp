@@ -53,7 +53,7 @@ size_t pcg_minv_bytes(int nfree);
 hipError_t pcg_launch_minv(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int nfree, double* Minv, int* bad);
 void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc);
 void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc, int first, int parity);
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int parity);
 void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc);
 void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_update(hipStream_t, const BaDev&);
@@ -316,7 +316,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         CCM_HIP(c, hipMemsetAsync(S.row_ptr.p, 0, (size_t)nfree * 8, st));
         sp_launch_row_ptr(st, S.ent_key2.as<unsigned>(), 2 * nb, nfree, S.row_ptr.as<int>());
         CCM_RESERVE(c, S.Hb, (36 * (size_t)nb + (size_t)n + 8) * 8);          // blocks, then bschur: one all-reduce covers both
-        CCM_RESERVE(c, S.Minv, pcg_minv_bytes(nfree)); CCM_RESERVE(c, S.pcg_w, 5 * (size_t)n * 8 + 64);
+        CCM_RESERVE(c, S.Minv, pcg_minv_bytes(nfree)); CCM_RESERVE(c, S.pcg_w, 6 * (size_t)n * 8 + 64);
         CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)n / 192 + 4) * 3 * 8 + 64);
         CCM_RESERVE(c, S.pcg_sc, 64 * 8);
         CCM_HIP(c, hipGetLastError());
@@ -328,7 +328,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // dense Cholesky for small systems (exact, and cheaper than PCG start-up), PCG on the packed blocks otherwise
     static const int dense_max = getenv("CCM_BA_DENSE_MAX") ? atoi(getenv("CCM_BA_DENSE_MAX")) : 1536;
     const bool use_pcg = n > dense_max;
-    // The PCG inner loop is three small dependent kernels per iteration and is launch-bound when issued one by
+    // The PCG inner loop is two small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
     const int pcg_chunk = 16;                     // even: the r.z slot parity is the same at the start of every chunk
     hipGraph_t pcg_graph = nullptr; hipGraphExec_t pcg_exec = nullptr;
@@ -338,7 +338,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
             for (int k = 0; k < pcg_chunk; k++)
                 pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0, k & 1);
+                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1);
             pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
             hipError_t e1 = hipStreamEndCapture(st, &pcg_graph);
             hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec, pcg_graph, nullptr, nullptr, 0) : e1;
@@ -445,7 +445,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                                 else {
                                     for (int k = 0; k < pcg_chunk; k++)
                                         pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k == 0, k & 1);
+                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1);
                                     pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
                                 }
                             }

@@ -252,16 +252,17 @@ __global__ __launch_bounds__(256) void k_pcg_cl_gather(const double* __restrict_
 }
 // in-place inverse of every cluster matrix by Gauss-Jordan without pivoting (SPD); unused rows of the last cluster
 // are made identity; a non-positive pivot raises `bad`
-__global__ __launch_bounds__(64) void k_pcg_cl_invert(double* __restrict__ Mc, int nfree, int* __restrict__ bad)
+__global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, int nfree, int* __restrict__ bad)
 {
-    __shared__ double a[PCG_CN][PCG_CN + 1], inv[PCG_CN][PCG_CN + 1];
+    // augmented [A | I] -> [I | A^-1]; column 2*PCG_CN+... padding of 1 keeps the row stride odd (bank conflicts)
+    __shared__ double a[PCG_CN][2 * PCG_CN + 1];
     __shared__ double fcol[PCG_CN];
     double* M = Mc + (long long)blockIdx.x * PCG_CN * PCG_CN;
     const int used = 6 * min(PCG_CL, nfree - (int)blockIdx.x * PCG_CL);
-    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 64) {
+    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 256) {
         const int r = i / PCG_CN, c = i - r * PCG_CN;
         a[r][c] = (r < used && c < used) ? M[i] : (r == c ? 1.0 : 0.0);
-        inv[r][c] = r == c ? 1.0 : 0.0;
+        a[r][PCG_CN + c] = r == c ? 1.0 : 0.0;
     }
     __syncthreads();
     bool ok = true;
@@ -269,22 +270,23 @@ __global__ __launch_bounds__(64) void k_pcg_cl_invert(double* __restrict__ Mc, i
         const double piv = a[k][k];
         if (!(piv > 0.0)) ok = false;
         const double ip = 1.0 / piv;
-        __syncthreads();
-        for (int j = threadIdx.x; j < 2 * PCG_CN; j += 64) { if (j < PCG_CN) a[k][j] *= ip; else inv[k][j - PCG_CN] *= ip; }
         if (threadIdx.x < PCG_CN) fcol[threadIdx.x] = a[threadIdx.x][k];
-        __syncthreads();
-        for (int e = threadIdx.x; e < PCG_CN * 2 * PCG_CN; e += 64) {
+        __syncthreads();                                         // everyone has read the pivot and the pivot column
+        // row k is scaled on the fly: a[i][j] -= a[i][k] * (a[k][j] / piv); row k itself becomes a[k][j] / piv
+        for (int e = threadIdx.x; e < PCG_CN * 2 * PCG_CN; e += 256) {
             const int i = e / (2 * PCG_CN), j = e - i * 2 * PCG_CN;
-            if (i == k) continue;
-            if (j < PCG_CN) a[i][j] -= fcol[i] * a[k][j]; else inv[i][j - PCG_CN] -= fcol[i] * inv[k][j - PCG_CN];
+            const double rk = a[k][j] * ip;
+            if (i != k) a[i][j] -= fcol[i] * rk;
         }
         __syncthreads();
+        for (int j = threadIdx.x; j < 2 * PCG_CN; j += 256) a[k][j] *= ip;
+        __syncthreads();
     }
-    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 64) M[i] = inv[i / PCG_CN][i % PCG_CN];
+    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 256) M[i] = a[i / PCG_CN][PCG_CN + i % PCG_CN];
     if (!ok && threadIdx.x == 0) atomicOr(bad, 1);
 }
 
-// state vector layout in `w`: x | r | z | p | Ap  (each n doubles); scalars in sc[]:
+// state vector layout in `w`: x | r | z | p (even iterations) | Ap | p (odd iterations)  (each n doubles); scalars in sc[]:
 //   sc[0] rz, sc[1] |b|^2, sc[2] |r|^2, sc[3] min p.Ap seen, sc[4] iterations
 #define PCG_UPD_TPB 192       // 4 clusters of PCG_CN scalars: a cluster never straddles two blocks
 static_assert(PCG_UPD_TPB % PCG_CN == 0, "a block must hold whole clusters");
@@ -305,44 +307,59 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restri
         double z = 0;
 #pragma unroll 8
         for (int k = 0; k < PCG_CN; k++) z += M[k * PCG_CN] * rs[base + k];       // symmetric: column li read with unit stride across lanes
-        w[o] = 0.0; w[n + o] = ri; w[2 * n + o] = z; w[3 * n + o] = z;
+        w[o] = 0.0; w[n + o] = ri; w[2 * n + o] = z; w[3 * n + o] = 0.0; w[5 * n + o] = 0.0;   // p = z + beta * 0 in the first mat-vec
         rz = ri * z; bb = ri * ri;
     }
     for (int s = 32; s >= 1; s >>= 1) { rz += __shfl_xor(rz, s, 64); bb += __shfl_xor(bb, s, 64); }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = rz; red[1][threadIdx.x >> 6] = bb; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + red[0][2];
-        part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + red[1][2];
+    if (threadIdx.x == 0) {                   // same layout as k_pcg_update: r.z, |r|^2, p.Ap
+        part[3 * blockIdx.x] = (red[0][0] + red[0][1]) + red[0][2];
+        part[3 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + red[1][2];
+        part[3 * blockIdx.x + 2] = 1e300;
     }
 }
 __global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ part, int nblk, double* __restrict__ sc)
 {
     if (threadIdx.x != 0) return;
     double rz = 0, bb = 0;
-    for (int i = 0; i < nblk; i++) { rz += part[2 * i]; bb += part[2 * i + 1]; }
+    for (int i = 0; i < nblk; i++) { rz += part[3 * i]; bb += part[3 * i + 1]; }
     sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0; sc[8] = rz; sc[9] = rz;
 }
 
-// Ap = A p, one workgroup per block row: thread = (entry slot 0..41, row component 0..5); the 42 slot sums of a
-// component are added in slot order by one lane (fixed order).  ~130 entries per row -> 3-4 steps per thread and
-// 8000 waves in flight instead of 2000, which is what hides the index->block->data dependent loads.
+// Direction update + mat-vec in one kernel, one workgroup per block row:  p = z + beta p_old  is formed on the fly for
+// the row's own pose and for every neighbour (p_old lives in the other of two alternating buffers, so no workgroup can
+// overwrite what another still reads), then Ap = A p.  beta = r.z (this iteration) / r.z (previous): every workgroup
+// re-reduces the ~60 partial sums of k_pcg_update itself (fixed order), the previous value comes from the alternating
+// slot sc[8 + parity] and block 0 leaves the current one in the other slot for k_pcg_update and the next iteration.
+// Thread = (entry slot 0..41, row component 0..5); the 42 slot sums of a component are added in slot order by one lane.
 __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb, const int* __restrict__ row_ptr, const unsigned* __restrict__ ent_key,
                                                   const unsigned* __restrict__ ent_val, int nfree, double* __restrict__ w, double* __restrict__ pap_part,
-                                                  int publish, int nblk_part, const double* __restrict__ part, double* __restrict__ sc)
+                                                  int nblk_part, const double* __restrict__ part, double* __restrict__ sc, int parity)
 {
     __shared__ double red[42][6];
-    // The scalars of the PREVIOUS iteration (r.z, |r|^2, p.Ap) are published here, after k_pcg_dir has consumed
-    // the old r.z and before this iteration's k_pcg_update reads the new one (kernel boundaries order both).
-    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
-        double rz = 0, rr = 0;
-        for (int i = 0; i < nblk_part; i++) { rz += part[3 * i]; rr += part[3 * i + 1]; }
-        const double pap = part[2];
-        sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;
-    }
+    __shared__ double s_beta;
     const int row = blockIdx.x;
     const long long n = 6LL * nfree;
-    const double* p = w + 3 * n;
+    if (threadIdx.x < 64) {
+        double rz = 0, rr = 0;
+        for (int i = threadIdx.x; i < nblk_part; i += 64) { rz += part[3 * i]; rr += part[3 * i + 1]; }
+        for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); }
+        if (threadIdx.x == 0) {
+            const double rz_prev = sc[8 + parity];
+            s_beta = rz_prev > 0.0 ? rz / rz_prev : 0.0;
+            if (row == 0) {                                        // scalars for k_pcg_update, the next iteration and the host
+                const double pap = part[2];
+                sc[8 + (parity ^ 1)] = rz;
+                sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;
+            }
+        }
+    }
+    __syncthreads();
+    const double beta = s_beta;
+    const double* z = w + 2 * n;
+    const double* p_old = w + (parity ? 3 : 5) * n;
+    double* p_new = w + (parity ? 5 : 3) * n;
     const int slot = threadIdx.x / 6, r = threadIdx.x - 6 * slot;
     if (slot < 42) {
         double acc = 0;
@@ -366,10 +383,11 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
                     continue;
                 }
                 const double* B = Hb + 36 * (long long)(v[q] & 0x7FFFFFFFu);
-                const double* x = p + 6 * (long long)col[q];
+                const double* zc = z + 6 * (long long)col[q];
+                const double* pc = p_old + 6 * (long long)col[q];
                 const bool tr = (v[q] & 0x80000000u) != 0u;
 #pragma unroll
-                for (int c = 0; c < 6; c++) { bv[q][c] = tr ? B[c * 6 + r] : B[r * 6 + c]; xv[q][c] = x[c]; }
+                for (int c = 0; c < 6; c++) { bv[q][c] = tr ? B[c * 6 + r] : B[r * 6 + c]; xv[q][c] = zc[c] + beta * pc[c]; }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -383,8 +401,11 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
         double tot = 0, pap = 0;
         if (threadIdx.x < 6) {
             for (int s2 = 0; s2 < 42; s2++) tot += red[s2][threadIdx.x];
-            w[4 * n + 6LL * row + threadIdx.x] = tot;
-            pap = tot * p[6LL * row + threadIdx.x];
+            const long long o = 6LL * row + threadIdx.x;
+            const double pn = z[o] + beta * p_old[o];
+            w[4 * n + o] = tot;
+            p_new[o] = pn;
+            pap = tot * pn;
         }
         for (int st = 4; st >= 1; st >>= 1) pap += __shfl_xor(pap, st, 64);     // lanes 0..7 (6,7 hold 0)
         if (threadIdx.x == 0) pap_part[row] = pap;
@@ -404,8 +425,8 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
     // everything this thread needs is requested before the reduction, so that all global loads overlap
     double r_old = 0, ap = 0, x_old = 0, p_old = 0;
-    if (o < n) { r_old = w[n + o]; ap = w[4 * n + o]; x_old = w[o]; p_old = w[3 * n + o]; }
-    const double rz_old = sc[8 + parity];
+    if (o < n) { r_old = w[n + o]; ap = w[4 * n + o]; x_old = w[o]; p_old = w[(parity ? 5 : 3) * n + o]; }   // this iteration's direction
+    const double rz_old = sc[8 + (parity ^ 1)];                     // this iteration's r.z, left there by k_pcg_spmv
     double s = 0;
 #pragma unroll 4
     for (int k = threadIdx.x; k < nfree; k += PCG_UPD_TPB) s += pap_part[k];
@@ -437,27 +458,6 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     }
 }
 
-// beta = rz_new / rz_old; p = z + beta p; publish the scalars (block 0)
-// r.z lives in two alternating slots sc[8], sc[9]: iteration `parity` reads its slot and block 0 writes the other,
-// so no block can see the new value while another still needs the old one.
-__global__ __launch_bounds__(256) void k_pcg_dir(int nfree, int nblk, double* __restrict__ w, const double* __restrict__ part, double* __restrict__ sc, int parity)
-{
-    __shared__ double red[4];
-    const long long n = 6LL * nfree;
-    const long long i = blockIdx.x * 256LL + threadIdx.x;
-    double zi = 0, pi = 0;
-    if (i < n) { zi = w[2 * n + i]; pi = w[3 * n + i]; }
-    const double rz_old = sc[8 + parity];
-    double rz = 0;
-    for (int k = threadIdx.x; k < nblk; k += 256) rz += part[3 * k];     // fixed assignment + fixed tree: reproducible
-    for (int st = 32; st >= 1; st >>= 1) rz += __shfl_xor(rz, st, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = rz;
-    __syncthreads();
-    rz = (red[0] + red[1]) + (red[2] + red[3]);
-    const double beta = rz_old > 0.0 ? rz / rz_old : 0.0;
-    if (i < n) w[3 * n + i] = zi + beta * pi;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc[8 + (parity ^ 1)] = rz;
-}
 __global__ __launch_bounds__(64) void k_pcg_scalars(int nblk, const double* __restrict__ part, double* __restrict__ sc)
 {
     if (threadIdx.x != 0) return;
@@ -538,7 +538,7 @@ hipError_t pcg_launch_minv(hipStream_t s, const double* Hb, const int* blk_row, 
     hipError_t e = hipMemsetAsync(Minv, 0, pcg_minv_bytes(nfree), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pcg_cl_gather, dim3(nblk(36LL * nb, 256)), dim3(256), 0, s, Hb, blk_row, blk_col, nb, Minv);
-    hipLaunchKernelGGL(k_pcg_cl_invert, dim3(ncl), dim3(64), 0, s, Minv, nfree, bad);
+    hipLaunchKernelGGL(k_pcg_cl_invert, dim3(ncl), dim3(256), 0, s, Minv, nfree, bad);
     return hipSuccess;
 }
 void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc)
@@ -547,14 +547,13 @@ void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfr
     hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part);
     hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, sc);
 }
-// `first` = this is the first iteration since pcg_launch_init or pcg_launch_publish (nothing pending to publish)
+// one PCG iteration = two kernels (direction + mat-vec, then the vector updates with the preconditioner)
 void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc, int first, int parity)
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int parity)
 {
     const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
-    hipLaunchKernelGGL(k_pcg_spmv, dim3(nfree), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, first ? 0 : 1, nb, part, sc);
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(nfree), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity);
     hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity);
-    hipLaunchKernelGGL(k_pcg_dir, dim3(nblk(6LL * nfree, 256)), dim3(256), 0, s, nfree, nb, w, part, sc, parity);
 }
 // publish the scalars of the last iteration (before the host reads them)
 void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc)

@@ -27,4 +27,4 @@ for n_pairs in (255, 10000):
     ctx.profile(False)
     per = ms / n
     print("variant=%s split=%s pairs=%d  %.3f ms/launch  %.2f Gdist/s  %.1f Mqueries/s  parity=%s" %
-          (os.environ.get("CCM_BF_VARIANT", "0"), os.environ.get("CCM_BF_SPLIT", "auto"), n_pairs, per, n_pairs * 1e6 / per / 1e6, n_pairs * 1000 / per / 1e3, ok))
+          (os.environ.get("CCM_BF_VARIANT", "3 (matrix cores)"), os.environ.get("CCM_BF_SPLIT", "auto"), n_pairs, per, n_pairs * 1e6 / per / 1e6, n_pairs * 1000 / per / 1e3, ok))

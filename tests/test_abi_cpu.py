@@ -97,3 +97,31 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(d, f), errors="replace").read()
                 assert "oracle_py" not in txt and "liboracle" not in txt and "orc_" not in txt, os.path.join(d, f)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (and as C++11), and a C program must link against the
+    library and call a host-only entry point without any C++ or HIP at the call site."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "ccm_hot.h"\n'
+                   '#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    unsigned char a[32] = {0}, b[32] = {0}; b[0] = 0x0F; b[31] = 0x80;\n'
+                   '    ccm_orb_params p = {1000, 1.2f, 8, 20, 7};\n'
+                   '    float sf[8], isf[8], s2[8], is2[8]; int nf[8], um[16];\n'
+                   '    if (ccm_orb_tables(&p, sf, isf, s2, is2, nf, um) != 0) return 2;\n'
+                   '    printf("%d %d %d\\n", ccm_descriptor_distance(a, b), nf[0], (int)sizeof(ccm_keypoint));\n'
+                   '    return 0;\n}\n')
+    inc = os.path.join(root, "include")
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        if shutil.which(cc) is None:
+            pytest.skip("no host compiler")
+        subprocess.check_call([cc, std, "-Wall", "-Wextra", "-pedantic", "-I", inc, "-fsyntax-only"] + (["-x", "c++"] if cc == "g++" else []) + [str(src)])
+    exe = tmp_path / "abi"
+    libdir = os.path.join(root, "motioncheck_ccm_slam_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lccm_hot", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["5", "217", "28"], out.stdout + out.stderr

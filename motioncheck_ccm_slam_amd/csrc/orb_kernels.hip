@@ -1157,11 +1157,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom g, const unsi
             const int kk = y >> 1;
             unsigned v;
             if ((y & 1) == 0)
-                v = od_dot2(d[kk + 3], 18u, od_dot2(d[kk + 2], 49u | (34u << 16), od_dot2(d[kk + 1], 49u | (55u << 16), od_dot2(d[kk], 18u | (34u << 16), 0u))));
+                v = od_dot2(d[kk + 3], 18u, od_dot2(d[kk + 2], 49u | (34u << 16), od_dot2(d[kk + 1], 49u | (55u << 16), od_dot2(d[kk], 18u | (34u << 16), 32768u))));
             else
-                v = od_dot2(d[kk + 3], 34u | (18u << 16), od_dot2(d[kk + 2], 55u | (49u << 16), od_dot2(d[kk + 1], 34u | (49u << 16), od_dot2(d[kk], 18u << 16, 0u))));
-            v = (v + 32768u) >> 16;
-            bl[y * OD_B_PITCH + lane] = (uint8_t)min(v, 255u);
+                v = od_dot2(d[kk + 3], 34u | (18u << 16), od_dot2(d[kk + 2], 55u | (49u << 16), od_dot2(d[kk + 1], 34u | (49u << 16), od_dot2(d[kk], 18u << 16, 32768u))));
+            bl[y * OD_B_PITCH + lane] = (uint8_t)min(v >> 16, 255u);     // the rounding constant 32768 is the accumulator's start value
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -145,52 +145,54 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double*
     }
 }
 
-// One wave per block.  Per step the wave fetches the operands of four pairs with ONE load per lane each (lanes
-// 0..17: Y_a = Hpl_a Dinv, lanes 18..35: Hpl_b; 288 bytes per pair), parks them in its LDS slice and every lane
-// (i,j) < 36 then reads the six values it needs from LDS.  Four fixed accumulation chains, combined as
-// (s0+s1)+(s2+s3): the result does not depend on scheduling.
+// One wave per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Y_a W_b^T
+// with Y_a = Hpl_a Dinv (6x3) and W_b = Hpl_b (6x3).  The sum over pairs is one GEMM with K = 3 x pairs:
+// [Y_a1 Y_a2 ...] (6 x K) times [W_b1 W_b2 ...]^T (K x 6), run on the f64 matrix cores as v_mfma_f64_16x16x4_f64
+// (M = N = 16 of which 6 are used, K = 4 per instruction: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]).
+// Four pairs = twelve k = three MFMAs per step (eight pairs per step measured slower); each lane gathers exactly the operand elements its (row, k) needs,
+// so nothing goes through LDS.  The accumulation order is the hardware's fixed k order: reproducible run to run.
+typedef double sp_v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                                                          const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb,
                                                          double* __restrict__ Hb)
 {
-    __shared__ double stage[4][4][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wv;
     if (b >= nb) return;
-    const int i = lane / 6, j = lane - 6 * i;              // meaningful for lane < 36
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const int i = lane & 15, kq = lane >> 4;                // operand row (< 6 used), k within an MFMA
     const int p0 = seg_start[b], p1 = seg_end[b];
-    double (*st)[36] = stage[wv];
-    for (int p = p0; p < p1; p += 4) {
-        double v[4];
+    sp_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+    // k = 4 m + kq of a step's twelve: pair kk / 3, column kk % 3 (fixed per lane for m = 0, 1, 2)
+    int pl[3], cl[3];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            v[q] = 0.0;
-            if (lane < 36 && p + q < p1) {
-                const unsigned long long pr = pairs[p + q];
-                v[q] = lane < 18 ? Y[18 * (long long)(unsigned)(pr >> 32) + lane]
-                                 : D.Hpl[18 * (long long)(unsigned)(pr & 0xFFFFFFFFu) + (lane - 18)];
+    for (int m = 0; m < 3; m++) { const int kk = 4 * m + kq; pl[m] = kk / 3; cl[m] = kk - 3 * pl[m]; }
+    for (int p = p0; p < p1; p += 4) {
+        double av[3], bv[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            av[m] = 0.0; bv[m] = 0.0;
+            if (i < 6 && p + pl[m] < p1) {
+                const unsigned long long pr = pairs[p + pl[m]];
+                av[m] = Y[18 * (long long)(unsigned)(pr >> 32) + 3 * i + cl[m]];
+                bv[m] = D.Hpl[18 * (long long)(unsigned)(pr & 0xFFFFFFFFu) + 3 * i + cl[m]];
             }
         }
-        if (lane < 36) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) st[q][lane] = v[q];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // this wave's LDS stores have landed
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 36) {
-            s0 += st[0][3 * i] * st[0][18 + 3 * j] + st[0][3 * i + 1] * st[0][19 + 3 * j] + st[0][3 * i + 2] * st[0][20 + 3 * j];
-            s1 += st[1][3 * i] * st[1][18 + 3 * j] + st[1][3 * i + 1] * st[1][19 + 3 * j] + st[1][3 * i + 2] * st[1][20 + 3 * j];
-            s2 += st[2][3 * i] * st[2][18 + 3 * j] + st[2][3 * i + 1] * st[2][19 + 3 * j] + st[2][3 * i + 2] * st[2][20 + 3 * j];
-            s3 += st[3][3 * i] * st[3][18 + 3 * j] + st[3][3 * i + 1] * st[3][19 + 3 * j] + st[3][3 * i + 2] * st[3][20 + 3 * j];
-        }
-        __builtin_amdgcn_wave_barrier();                   // reads done before the next step overwrites the slice
+        for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[m], acc, 0, 0, 0);
     }
-    if (lane >= 36) return;
-    const int r = blk_row[b], c = blk_col[b];
-    const double base = r == c ? D.Hpp[36 * (long long)r + lane] : 0.0;
-    Hb[36 * (long long)b + lane] = base - ((s0 + s1) + (s2 + s3));
+    // C/D: column = lane & 15, row = (lane >> 4) + 4 * reg
+    const int c = lane & 15;
+    if (c >= 6) return;
+    const int rb = blk_row[b], cb = blk_col[b];
+#pragma unroll
+    for (int reg = 0; reg < 2; reg++) {
+        const int r = kq + 4 * reg;
+        if (r < 6) {
+            const double base = rb == cb ? D.Hpp[36 * (long long)rb + 6 * r + c] : 0.0;
+            Hb[36 * (long long)b + 6 * r + c] = base - acc[reg];
+        }
+    }
 }
 
 // one wave per free pose: bs = bp - sum over its edges of Hpl_e db(l_e), fixed order

@@ -97,7 +97,7 @@ struct OrbState {
     OrbTables tab{};
     OrbGeom geom{};
     std::vector<OrbCell> cells;
-    std::vector<OrbBand> bands; size_t band_lds = 0; bool fused = true; int surv_cap = 1024;
+    std::vector<OrbBand> bands; size_t band_lds = 0; bool fused = true; int surv_cap = 1024; hipStream_t copy_stream = nullptr; hipEvent_t copy_done = nullptr;
     DevBuf geom_dev, cells_dev, tables_dev, bands_dev;
     DevBuf pyr, smap, slots, cell_count, keysA, keysB, sel, sel_count, status;
     DevBuf img0;                   // staging for the host-pointer entry point
@@ -113,6 +113,8 @@ void orb_state_free(OrbState* s)
     DevBuf* all[] = { &s->geom_dev, &s->cells_dev, &s->tables_dev, &s->bands_dev, &s->pyr, &s->smap, &s->slots, &s->cell_count,
                       &s->keysA, &s->keysB, &s->sel, &s->sel_count, &s->status, &s->img0, &s->kps, &s->desc, &s->counts };
     for (DevBuf* b : all) b->release();
+    if (s->copy_done) (void)hipEventDestroy(s->copy_done);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     delete s;
 }
 
@@ -292,30 +294,33 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
     return CCM_OK;
 }
 
-static int orb_run(ccm_ctx* c, const uint8_t* img_dev, int stride, size_t image_stride)
+// Runs the pipeline on frames [frame0, frame0 + nrun) of the prepared batch (all of it by default).
+static int orb_run(ccm_ctx* c, const uint8_t* img_dev, int stride, size_t image_stride, int frame0 = 0, int nrun = -1)
 {
     OrbState& S = *c->orb;
     OrbGeom& G = S.geom;
     // the geometry table (incl. level 0's image pointer) travels by value in the kernel arguments
     G.lv[0].img = img_dev; G.lv[0].pitch = stride; G.lv[0].plane = (long long)image_stride;
+    G.frame0 = frame0;
+    if (nrun < 0) nrun = S.nframes - frame0;
     const OrbGeom& gd = G;
     const OrbCell* cd = S.cells_dev.as<OrbCell>();
     hipStream_t st = c->stream;
-    CCM_HIP(c, hipMemsetAsync(S.status.p, 0, 4, st));
-    for (int l = 1; l < G.nlevels; l++) { ProfScope ps(c, CCM_PROF_RESIZE); orb_launch_resize(st, gd, l, G.lv[l].w, G.lv[l].h, S.nframes); }
+    if (frame0 == 0) CCM_HIP(c, hipMemsetAsync(S.status.p, 0, 4, st));
+    for (int l = 1; l < G.nlevels; l++) { ProfScope ps(c, CCM_PROF_RESIZE); orb_launch_resize(st, gd, l, G.lv[l].w, G.lv[l].h, nrun); }
     if (S.fused && !S.bands.empty()) {
         ProfScope ps(c, CCM_PROF_FAST_SCORE);
-        orb_launch_fast_cells(st, gd, cd, S.bands_dev.as<OrbBand>(), (int)S.bands.size(), S.nframes, S.band_lds, S.surv_cap, S.slots.as<unsigned>(), S.cell_count.as<int>());
+        orb_launch_fast_cells(st, gd, cd, S.bands_dev.as<OrbBand>(), (int)S.bands.size(), nrun, S.band_lds, S.surv_cap, S.slots.as<unsigned>(), S.cell_count.as<int>());
     } else {
-        { ProfScope ps(c, CCM_PROF_FAST_SCORE); orb_launch_score(st, gd, G.ntiles, S.nframes); }
-        if (G.ncells > 0) { ProfScope ps(c, CCM_PROF_CELL_NMS); orb_launch_nms(st, gd, cd, G.ncells, S.nframes, S.slots.as<unsigned>(), S.cell_count.as<int>()); }
+        { ProfScope ps(c, CCM_PROF_FAST_SCORE); orb_launch_score(st, gd, G.ntiles, nrun); }
+        if (G.ncells > 0) { ProfScope ps(c, CCM_PROF_CELL_NMS); orb_launch_nms(st, gd, cd, G.ncells, nrun, S.slots.as<unsigned>(), S.cell_count.as<int>()); }
     }
     { ProfScope ps(c, CCM_PROF_OCTREE);
-    orb_launch_octree(st, gd, cd, G.nlevels, S.nframes, G.list_cap, S.slots.as<unsigned>(), S.cell_count.as<int>(),
+    orb_launch_octree(st, gd, cd, G.nlevels, nrun, G.list_cap, S.slots.as<unsigned>(), S.cell_count.as<int>(),
                       S.keysA.as<unsigned>(), S.keysB.as<unsigned>(), S.sel.as<unsigned>(), S.sel_count.as<int>(),
                       S.status.as<int>()); }
     { ProfScope ps(c, CCM_PROF_ORIENT_DESC);
-    orb_launch_orient_desc(st, gd, G.out_per_frame, S.nframes, S.sel.as<unsigned>(), S.sel_count.as<int>(),
+    orb_launch_orient_desc(st, gd, G.out_per_frame, nrun, S.sel.as<unsigned>(), S.sel_count.as<int>(),
                            S.kps.as<ccm_keypoint>(), S.desc.as<uint8_t>(), S.counts.as<int>(), S.max_per_image,
                            S.status.as<int>()); }
     CCM_HIP(c, hipGetLastError());
@@ -405,18 +410,35 @@ int ccm_orb_extract(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img, int
     const int pitch = (int)align_up(w, 64);
     const size_t plane = (size_t)pitch * h;
     CCM_RESERVE(c, S.img0, plane * n_images);
-    if (n_images == 1 || image_stride == (size_t)stride * h) {
-        CCM_HIP(c, hipMemcpy2DAsync(S.img0.p, pitch, img, stride, w, (size_t)h * n_images, hipMemcpyHostToDevice, c->stream));
-        // rows of consecutive images are consecutive in both layouts only when plane == pitch*h on the device side
-    } else {
-        for (int i = 0; i < n_images; i++)
-            CCM_HIP(c, hipMemcpy2DAsync(S.img0.as<char>() + plane * i, pitch, img + image_stride * i, stride, w, h,
-                                        hipMemcpyHostToDevice, c->stream));
-    }
     int rc = orb_prepare(c, p, w, h, n_images, max_per_image);
     if (rc) return rc;
-    rc = orb_run(c, S.img0.as<uint8_t>(), pitch, plane);
-    if (rc) return rc;
+    // Host buffers: the frames go up in chunks on a copy stream while the previous chunk is being extracted (the
+    // upload is ~2/3 of the whole call for 752x480 frames).  Small batches go up in one piece.
+    static const int chunk_frames = getenv("CCM_ORB_CHUNK") ? std::max(1, atoi(getenv("CCM_ORB_CHUNK"))) : 64;
+    const int n_chunks = n_images >= 2 * chunk_frames ? (n_images + chunk_frames - 1) / chunk_frames : 1;
+    if (n_chunks > 1 && !S.copy_stream) {
+        CCM_HIP(c, hipStreamCreateWithFlags(&S.copy_stream, hipStreamNonBlocking));
+        CCM_HIP(c, hipEventCreateWithFlags(&S.copy_done, hipEventDisableTiming));
+    }
+    const bool contiguous = n_images == 1 || image_stride == (size_t)stride * h;
+    for (int ck = 0; ck < n_chunks; ck++) {
+        const int f0 = (int)((long long)n_images * ck / n_chunks), f1 = (int)((long long)n_images * (ck + 1) / n_chunks);
+        hipStream_t up = n_chunks > 1 ? S.copy_stream : c->stream;
+        if (contiguous) {
+            // rows of consecutive images are consecutive in both layouts (device plane == pitch * h)
+            CCM_HIP(c, hipMemcpy2DAsync(S.img0.as<char>() + plane * f0, pitch, img + image_stride * f0, stride, w, (size_t)h * (f1 - f0),
+                                        hipMemcpyHostToDevice, up));
+        } else {
+            for (int i = f0; i < f1; i++)
+                CCM_HIP(c, hipMemcpy2DAsync(S.img0.as<char>() + plane * i, pitch, img + image_stride * i, stride, w, h, hipMemcpyHostToDevice, up));
+        }
+        if (n_chunks > 1) {
+            CCM_HIP(c, hipEventRecord(S.copy_done, up));
+            CCM_HIP(c, hipStreamWaitEvent(c->stream, S.copy_done, 0));
+        }
+        rc = orb_run(c, S.img0.as<uint8_t>(), pitch, plane, f0, f1 - f0);
+        if (rc) return rc;
+    }
     return ccm_orb_fetch(c, kps, desc, counts);
 }
 

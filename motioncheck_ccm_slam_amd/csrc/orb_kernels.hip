@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom g, int level)
     const int x4 = (blockIdx.x * 64 + lane) * 4;
     // everything that depends on the row only is wave-uniform: kept in scalar registers
     const int yb = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RS_ROWS;
-    const int f = blockIdx.z;
+    const int f = blockIdx.z + g.frame0;
     if (yb >= D.h) return;
     const uint8_t* src = S.img + (long long)f * S.plane;
     uint8_t* dstp = const_cast<uint8_t*>(D.img) + (long long)f * D.plane;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const OrbGeom g)
     const OrbLevel& L = g.lv[level];
     t -= L.tile_first;
     const int tx0 = (t % L.tiles_x) * ST_W, ty0 = (t / L.tiles_x) * ST_H;
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + g.frame0;
     const uint8_t* img = L.img + (long long)f * L.plane;
     if (threadIdx.x == 0) nsurv = 0;
     for (int i = threadIdx.x; i < ST_H * ST_W / 4; i += 256) reinterpret_cast<unsigned*>(&outt[0][0])[i] = 0u;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int ci = blockIdx.x * 4 + wv;
     if (ci >= g.ncells) return;
-    const int f = blockIdx.y;
+    const int f = blockIdx.y + g.frame0;
     const OrbCell c = cells[ci];
     const OrbLevel& L = g.lv[c.level];
     const int rx0 = c.x0 + 3, ry0 = c.y0 + 3, rw = c.cw - 6, rh = c.ch - 6;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
     const OrbBand B = bands[blockIdx.x];
-    const int f = blockIdx.y, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const int f = blockIdx.y + g.frame0, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const OrbLevel& L = g.lv[B.level];
     const int P = B.pitch, bh = B.bh, PW = P >> 2;
     uint8_t* T = fc_smem;                                   // pixels  [bh][P]
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // blockIdx.y = level: the long-running fine levels are dispatched first
-    const int level = blockIdx.y, f = blockIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
+    const int level = blockIdx.y, f = blockIdx.x + g.frame0, lane = lane_id(), wv = threadIdx.x >> 6;
     const OrbLevel& L = g.lv[level];
     const int cap = g.list_cap;                                          // multiple of 16
     OctNodes cur = oct_carve(smem, cap);
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom g, const unsi
     }
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int slot = blockIdx.x * 4 + wv, f = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wv, f = blockIdx.y + g.frame0;
     if (slot >= g.out_per_frame) return;
     // slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
     int level = 0;

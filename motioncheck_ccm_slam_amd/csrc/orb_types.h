@@ -46,6 +46,7 @@ struct OrbBand {
 
 struct OrbGeom {
     int nlevels, ncells, ntiles;
+    int frame0;              // first frame of this launch: kernels index frame blockIdx + frame0 (chunked host-buffer pipeline)
     int ini_th, min_th;
     int slots_per_frame;     // sum of slot_cap
     int keys_per_frame;      // sum of key_cap

@@ -35,6 +35,12 @@ sf = ex.GetScaleFactors(); n = len(fr.kx)
 rng = np.random.default_rng(0)
 m = ORBmatcher(0.8, ctx=ctx)
 
+# the extractor through host buffers (what cslam::ORBextractor::operator() hands over): H2D of the frames, kernels, D2H
+frames = synth.frames(0, 256)
+t_host = timed(lambda: ex.extract_batch(frames), 3)
+out["A_extract_host_buffers"] = {"frames": 256, "ms": round(t_host * 1e3, 3), "Mfeatures_per_s": round(256 * 1000 / t_host / 1e6, 2),
+                                 "note": "pageable host memory in, keypoints + descriptors out; the resident-input rate is bench.py's value"}
+
 # F1: SearchByProjection(Frame, map points): 2000 map points against one frame
 nmp = 2000
 src = rng.integers(0, n, nmp)

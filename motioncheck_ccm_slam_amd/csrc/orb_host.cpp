@@ -225,7 +225,7 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
         const int xa = (c0.x0 - 4) & ~3;
         int pitch = 0;
         while (b < S.cells.size() && S.cells[b].level == c0.level && S.cells[b].y0 == c0.y0) {
-            const int p2 = (int)align_up((size_t)(S.cells[b].x0 + S.cells[b].cw + 4 - xa), 4);
+            const int p2 = (int)align_up((size_t)(S.cells[b].x0 + S.cells[b].cw + 4 - xa), 16);   // 16: the tile is staged 16 bytes per lane
             if (b > a && p2 > pcap) break;
             pitch = p2; b++;
         }

@@ -443,7 +443,28 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     const bool dword_ok = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)L.pitch) & 3) == 0 && L.pitch >= ((L.w + 3) & ~3);
     // i / PW by multiply-shift: exact for i < 2^20 / PW (i <= 65 * 64 here)
     const unsigned pw_inv = (1u << 20) / (unsigned)PW + 1u;
-    if (dword_ok) {
+    if (dword_ok && (P & 15) == 0) {
+        // 16 bytes per lane: one global load and two ds_write_b128 (pixels, zeroed scores) per 16 pixels; the last
+        // chunks of a row are clamped dword by dword
+        const int wmax = ((L.w - 1) & ~3);
+        const int PQ = P >> 4;
+        const unsigned pq_inv = (1u << 20) / (unsigned)PQ + 1u;   // i / PQ exact for i < 2^20 / PQ
+        for (int i = tid; i < bh * PQ; i += 256) {
+            const int ly = (int)(((unsigned)i * pq_inv) >> 20), lq = i - ly * PQ;
+            const int gy = min(B.y0 + ly, L.h - 1), gx = B.xa + 16 * lq;
+            const uint8_t* rowp = img + (long long)gy * L.pitch;
+            uint4 v;
+            if (gx + 12 <= wmax) __builtin_memcpy(&v, rowp + gx, 16);
+            else {
+                v.x = *reinterpret_cast<const unsigned*>(rowp + min(gx, wmax));
+                v.y = *reinterpret_cast<const unsigned*>(rowp + min(gx + 4, wmax));
+                v.z = *reinterpret_cast<const unsigned*>(rowp + min(gx + 8, wmax));
+                v.w = *reinterpret_cast<const unsigned*>(rowp + min(gx + 12, wmax));
+            }
+            reinterpret_cast<uint4*>(T)[i] = v;
+            reinterpret_cast<uint4*>(S)[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else if (dword_ok) {
         const int wmax = ((L.w - 1) & ~3);
         for (int i = tid; i < bh * PW; i += 256) {
             const int ly = (int)(((unsigned)i * pw_inv) >> 20), lx = i - ly * PW;

@@ -217,7 +217,7 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
     static const bool want_fused = !(getenv("CCM_ORB_FUSED") && atoi(getenv("CCM_ORB_FUSED")) == 0);
     S.fused = want_fused;
     static const int pcap = getenv("CCM_FC_PCAP") ? std::min(atoi(getenv("CCM_FC_PCAP")), 256) : 144;   // measured: 112 0.576, 128 0.558, 144 0.532, 160 0.574 ms      // pitch <= 256: one dword per lane
-    static const int scap = getenv("CCM_FC_SURV") ? atoi(getenv("CCM_FC_SURV")) : 2048;
+    static const int scap = getenv("CCM_FC_SURV") ? atoi(getenv("CCM_FC_SURV")) : 3072;      // two row blocks per 30-row band (measured best)
     S.surv_cap = scap;
     for (size_t a = 0; a < S.cells.size();) {
         size_t b = a;

@@ -484,7 +484,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     const OrbCell cfirst = cells[B.cell_first], clast = cells[B.cell_first + B.ncells - 1];
     const int c_lo = cfirst.x0 + 3 - B.xa, c_hi = clast.x0 + clast.cw - 3 - B.xa;
     const int t_lo = min(g.ini_th, g.min_th);
-    const int RB = max(1, FC_SURV / P);                      // rows per block: at most FC_SURV pixels
+    // rows per block: at most FC_SURV pixels, the detection rows dealt evenly to the blocks
+    const int rb_max = max(1, FC_SURV / P), n_rblk = (bh - 6 + rb_max - 1) / rb_max;
+    const int RB = n_rblk > 0 ? (bh - 6 + n_rblk - 1) / n_rblk : 1;
     // dwords that hold at least one detection column and have both neighbours inside the row
     const int dw_lo = max(1, c_lo >> 2);
     const int dw_hi = min(PW - 2, (c_hi - 1) >> 2);

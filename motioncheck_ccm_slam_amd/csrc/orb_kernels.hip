@@ -1072,16 +1072,19 @@ __device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc
     return __builtin_amdgcn_udot2(__builtin_bit_cast(od_us2, a), __builtin_bit_cast(od_us2, w), acc, false);
 }
 
-__global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
+#ifndef OD_WAVES
+#define OD_WAVES 4               // keypoints (waves) per workgroup
+#endif
+__global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
                                                      const int* __restrict__ sel_count,
                                                      ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                      int* __restrict__ counts, int max_per_image, int* __restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4][OD_WAVE_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[OD_WAVES][OD_WAVE_LDS_PAD];
     // IC_Angle weights per |v| and patch dword k (columns 4k..4k+3, u = column - 21):
     //   wone = 1 inside the disc row, wu = u + 16 inside (so that sum u*I = dot(wu) - 16*dot(wone) stays unsigned)
     __shared__ unsigned wone[16][11], wu[16][11];
-    for (int i = threadIdx.x; i < 16 * 11; i += 256) {
+    for (int i = threadIdx.x; i < 16 * 11; i += 64 * OD_WAVES) {
         const int av = i / 11, k = i - av * 11;
         const int lim = g.umax[av];
         unsigned a = 0, b = 0;
@@ -1093,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbGeom g, const unsi
     }
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int slot = blockIdx.x * 4 + wv, f = blockIdx.y + g.frame0;
+    const int slot = blockIdx.x * OD_WAVES + wv, f = blockIdx.y + g.frame0;
     if (slot >= g.out_per_frame) return;
     // slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
     int level = 0;
@@ -1257,6 +1260,6 @@ void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_fra
                             const int* sel_count, ccm_keypoint* kps, uint8_t* desc, int* counts, int max_per_image,
                             int* status)
 {
-    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + 3) / 4, nframes), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + OD_WAVES - 1) / OD_WAVES, nframes), dim3(64 * OD_WAVES), 0, s,
                        g_dev, sel, sel_count, kps, desc, counts, max_per_image, status);
 }

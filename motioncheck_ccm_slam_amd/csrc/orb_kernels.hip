@@ -410,8 +410,11 @@ __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 
 // PACKED: the rejection test on two pixels per register with the packed 16-bit VALU (v_pk_sub_u16 / v_pk_max_u16 /
 // v_pk_min_u16): |v - n| <= t  <=>  (u16)(v + t - n) <= 2t.
+#ifndef FC_TPB
+#define FC_TPB 256              // threads per band workgroup (measured: 192 0.56, 256 0.52, 320 0.75, 384 0.82 ms)
+#endif
 template <bool PACKED>
-__global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
+__global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
                                                     unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
         const int wmax = ((L.w - 1) & ~3);
         const int PQ = P >> 4;
         const unsigned pq_inv = (1u << 20) / (unsigned)PQ + 1u;   // i / PQ exact for i < 2^20 / PQ
-        for (int i = tid; i < bh * PQ; i += 256) {
+        for (int i = tid; i < bh * PQ; i += FC_TPB) {
             const int ly = (int)(((unsigned)i * pq_inv) >> 20), lq = i - ly * PQ;
             const int gy = min(B.y0 + ly, L.h - 1), gx = B.xa + 16 * lq;
             const uint8_t* rowp = img + (long long)gy * L.pitch;
@@ -466,14 +469,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
         }
     } else if (dword_ok) {
         const int wmax = ((L.w - 1) & ~3);
-        for (int i = tid; i < bh * PW; i += 256) {
+        for (int i = tid; i < bh * PW; i += FC_TPB) {
             const int ly = (int)(((unsigned)i * pw_inv) >> 20), lx = i - ly * PW;
             const int gy = min(B.y0 + ly, L.h - 1), gx = min(B.xa + 4 * lx, wmax);
             reinterpret_cast<unsigned*>(T)[i] = *reinterpret_cast<const unsigned*>(img + (long long)gy * L.pitch + gx);
             reinterpret_cast<unsigned*>(S)[i] = 0u;
         }
     } else {
-        for (int i = tid; i < bh * P; i += 256) {
+        for (int i = tid; i < bh * P; i += FC_TPB) {
             const int ly = i / P, lx = i - ly * P;
             const int gy = min(B.y0 + ly, L.h - 1), gx = min(B.xa + lx, L.w - 1);
             T[i] = img[(long long)gy * L.pitch + gx];
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
         __syncthreads();
         const int r1 = min(r0 + RB, bh - 3);
         const int items = (r1 - r0) * PW;
-        for (int it0 = 0; it0 < items; it0 += 256) {           // uniform trip count: the ballots below need whole waves
+        for (int it0 = 0; it0 < items; it0 += FC_TPB) {           // uniform trip count: the ballots below need whole waves
             const int it = it0 + tid;
             const int rr = (int)(((unsigned)it * pw_inv) >> 20);
             const int row = r0 + rr, dw = it - rr * PW;
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
         }
         __syncthreads();
         const int ns = abl == 2 ? 0 : min(*nsurv, FC_SURV);      // abl 2: no scoring
-        for (int si = tid; si < ns; si += 256) {
+        for (int si = tid; si < ns; si += FC_TPB) {
             const int pos = surv[si];
             const uint8_t* c = T + pos;
             const int v = c[0];
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
     const int rh = bh - 6;
     bool listed = g.min_th <= g.ini_th && nnz <= FC_NZ && B.ncells <= FC_CELLS;
     if (listed) {
-        for (int e = tid; e < nnz; e += 256) {
+        for (int e = tid; e < nnz; e += FC_TPB) {
             const int pos = nz[e];
             const int row = pos / P, col = pos - row * P;
             int ci = -1;
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
         const int nk = nsurv[2];
         listed = nk <= FC_KEPT;
         if (listed) {
-            for (int e = tid; e < nk; e += 256) {
+            for (int e = tid; e < nk; e += FC_TPB) {
                 const unsigned me = kept[e];
                 const int ci = (int)(me >> 20);
                 const unsigned th = (unsigned)(cell_hi[ci] > 0 ? g.ini_th : g.min_th);      // :978-984: ini first, else min
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const OrbGeom g, const OrbCe
         }
     }
     // ---- per cell: threshold choice, strict 3x3 NMS inside the cell's detection rectangle, ordered compaction
-    for (int ci = wv; ci < B.ncells; ci += 4) {
+    for (int ci = wv; ci < B.ncells; ci += FC_TPB / 64) {
         const OrbCell c = cells[B.cell_first + ci];
         const int rw = c.cw - 6, rh = c.ch - 6;
         int* count_out = cell_count + (long long)f * g.ncells + B.cell_first + ci;
@@ -1245,8 +1248,8 @@ void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* c
 {
     static const bool packed = !(getenv("CCM_FC_PACKED") && atoi(getenv("CCM_FC_PACKED")) == 0);
     static const int abl = getenv("CCM_FC_ABL") ? atoi(getenv("CCM_FC_ABL")) : 0;     // timing ablations only (results are wrong)
-    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
-    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(256), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
+    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
+    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
 }
 size_t orb_fast_cells_lds(int pitch, int bh, int surv_cap) { return fc_lds_bytes(pitch, bh, surv_cap); }
 void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,

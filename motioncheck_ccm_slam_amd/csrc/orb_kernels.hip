@@ -2,8 +2,9 @@
 //
 // Pipeline per batch (all frames of the batch in every launch):
 //   k_pyr_resize  x (nlevels-1)   cv::resize INTER_LINEAR 8u          ORBextractor.cpp:1293
-//   k_fast_score                  FAST-9/16 corner score of every px  :978-984 (cv::FAST)
-//   k_cell_nms                    per-cell threshold choice + 3x3 NMS :957-998
+//   k_fast_cells                  FAST-9/16 score + per-cell threshold :957-998, :978-984 (cv::FAST)
+//                                 choice + 3x3 NMS, fused on cell-row bands (scores stay in LDS)
+//     (k_fast_score + k_cell_nms: the same in two kernels through a score map, for cells wider than one LDS tile)
 //   k_octree                      DistributeOctTree                   :707-931
 //   k_orient_desc                 IC_Angle + 7x7 blur + rBRIEF        :68-95, :1259, :100-316
 // Wavefront = 64 everywhere; ballots are 64-bit.

@@ -117,8 +117,15 @@ __global__ __launch_bounds__(THREADS) void k_hamming_bf(
 // workgroup into LDS (double-buffered) and read back as ds_read_b128.
 typedef int hm_v4i __attribute__((ext_vector_type(4)));
 typedef int hm_v16i __attribute__((ext_vector_type(16)));
-#define HM_QW 64                 // queries per wave (two 32-column blocks)
+#ifndef HM_CB
+#define HM_CB 2                  // 32-query column blocks per wave; measured (CB, waves) at 10 k pairs: (2,4) 2.55 ms,
+                                 // (1,8) 2.72, (1,4) 3.09, (2,8) 3.13, (4,4) 8.94 (spills)
+#endif
+#ifndef HM_WAVES
 #define HM_WAVES 4
+#endif
+#define HM_QW (32 * HM_CB)       // queries per wave
+#define HM_TPB (64 * HM_WAVES)
 #define HM_SENT 0x3FFFFFFF       // key of "no train": larger than every real key, index field 0xFFFF
 #define HM_MAX_NT 2048           // train rows whose row words fit the LDS table (the launcher falls back beyond)
 
@@ -135,7 +142,7 @@ __device__ __forceinline__ hm_v4i hm_expand16(unsigned hw, unsigned mul)
 }
 
 // 4 workgroups per CU (<= 128 registers per lane): 255 pairs x 4 live query blocks = 1020 workgroups fit in ONE round
-__global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
+__global__ __launch_bounds__(HM_TPB, 1024 / HM_TPB) void k_hamming_mfma(
     const uint8_t* __restrict__ q, long long q_pair_bytes, const uint8_t* __restrict__ t, long long t_pair_bytes,
     int nq, int nt, const int* __restrict__ nq_n, const int* __restrict__ nt_n, int q_blocks,
     int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_dist)
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
     const unsigned* tp = reinterpret_cast<const unsigned*>(t + (long long)pair * t_pair_bytes);
     const int q0 = qblk * (HM_QW * HM_WAVES) + wv * HM_QW;              // this wave's first query
     if (qblk * (HM_QW * HM_WAVES) >= nqp) {                              // whole block past the live queries: defaults only
-        for (int i = tid; i < HM_QW * HM_WAVES; i += 64 * HM_WAVES) {
+        for (int i = tid; i < HM_QW * HM_WAVES; i += HM_TPB) {
             const int qi = qblk * (HM_QW * HM_WAVES) + i;
             if (qi < nq) { const long long o = (long long)pair * nq + qi; best_idx[o] = -1; best_dist[o] = 256; second_dist[o] = 256; }
         }
@@ -158,10 +165,10 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
     }
 
     // ---- B fragments of the wave's 64 queries (0 / -1 bytes) and their popcounts, kept in registers
-    hm_v4i bq[2][8];
-    int pa[2];
+    hm_v4i bq[HM_CB][8];
+    int pa[HM_CB];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
+    for (int cb = 0; cb < HM_CB; cb++) {
         const int qi = q0 + 32 * cb + r;
         unsigned d[8];
         int pc = 0;
@@ -171,22 +178,36 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
 #pragma unroll
         for (int s = 0; s < 8; s++) bq[cb][s] = hm_expand16((d[s] >> (16 * h)) & 0xFFFFu, 255u);
     }
-    int m1[2] = { HM_SENT, HM_SENT }, m2[2] = { HM_SENT, HM_SENT };
+    int m1[HM_CB], m2[HM_CB];
+#pragma unroll
+    for (int cb = 0; cb < HM_CB; cb++) { m1[cb] = HM_SENT; m2[cb] = HM_SENT; }
 
     // ---- staging of one 32-train tile: thread p expands dword s = p >> 5 of train r = p & 31 into the two
     //      lane-half fragments of k-step s; threads 0..31 also make the row words.  The raw words are fetched one
     //      tile ahead (issued before the MFMAs of the current tile) so that no wave waits on a global load.
+    // fragment f of a tile (512 of them): lane half f >> 8, k-step (f >> 5) & 7, train f & 31; thread t owns
+    // fragments t, t + HM_TPB, ... (with 256 threads: both halves of one dword)
+    constexpr int HM_FPT = (512 + HM_TPB - 1) / HM_TPB;
+    struct Raw { unsigned v[HM_FPT]; };
     auto fetch = [&](int tile) {
-        const int tr = tile * 32 + (tid & 31);
-        return tr < ntp ? tp[8 * (long long)tr + (tid >> 5)] : 0u;
+        Raw x;
+#pragma unroll
+        for (int j = 0; j < HM_FPT; j++) {
+            const int fi = tid + j * HM_TPB;
+            const int tr = tile * 32 + (fi & 31);
+            x.v[j] = (fi < 512 && tr < ntp) ? tp[8 * (long long)tr + ((fi >> 5) & 7)] : 0u;
+        }
+        return x;
     };
-    auto stage = [&](unsigned dw, int buf) {
-        const int s = tid >> 5;
-        frag[buf][s][tid & 31] = hm_expand16(dw & 0xFFFFu, 1u);
-        frag[buf][s][32 + (tid & 31)] = hm_expand16(dw >> 16, 1u);
+    auto stage = [&](const Raw& x, int buf) {
+#pragma unroll
+        for (int j = 0; j < HM_FPT; j++) {
+            const int fi = tid + j * HM_TPB;
+            if (fi < 512) frag[buf][(fi >> 5) & 7][32 * (fi >> 8) + (fi & 31)] = hm_expand16((x.v[j] >> (16 * (fi >> 8))) & 0xFFFFu, 1u);
+        }
     };
     // row words of all trains, once per workgroup
-    for (int tr = tid; tr < ((ntp + 31) & ~31); tr += 64 * HM_WAVES) {
+    for (int tr = tid; tr < ((ntp + 31) & ~31); tr += HM_TPB) {
         int w = HM_SENT;
         if (tr < ntp) {
             const uint4* d = reinterpret_cast<const uint4*>(tp + 8 * (long long)tr);
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
     }
     const int ntiles = (ntp + 31) >> 5;
     const bool wave_live = q0 < nqp;                                    // waves past the live queries only help staging
-    unsigned nxt = fetch(0);
+    Raw nxt = fetch(0);
     if (ntiles > 0) stage(nxt, 0);
     nxt = fetch(1);
     __syncthreads();
@@ -207,22 +228,25 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
         if (tile + 1 < ntiles) stage(nxt, buf ^ 1);
         if (tile + 2 < ntiles) nxt = fetch(tile + 2);
         if (wave_live) {
-            hm_v16i acc0 = {}, acc1 = {};
+            hm_v16i acc[HM_CB];
+#pragma unroll
+            for (int cb = 0; cb < HM_CB; cb++) acc[cb] = hm_v16i{};
 #pragma unroll
             for (int s = 0; s < 8; s++) {
                 const hm_v4i a = frag[buf][s][lane];
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < HM_CB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[cb][s], acc[cb], 0, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const hm_v4i w4 = *reinterpret_cast<const hm_v4i*>(&wall[32 * tile + 8 * g + 4 * h]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int k0 = (int)(((unsigned)acc0[4 * g + e] << 17) + (unsigned)w4[e]);
-                    const int k1 = (int)(((unsigned)acc1[4 * g + e] << 17) + (unsigned)w4[e]);
-                    m2[0] = max(min(m1[0], m2[0]), min(max(m1[0], m2[0]), k0)); m1[0] = min(m1[0], k0);     // v_med3_i32, v_min_i32
-                    m2[1] = max(min(m1[1], m2[1]), min(max(m1[1], m2[1]), k1)); m1[1] = min(m1[1], k1);
+#pragma unroll
+                    for (int cb = 0; cb < HM_CB; cb++) {
+                        const int kx = (int)(((unsigned)acc[cb][4 * g + e] << 17) + (unsigned)w4[e]);
+                        m2[cb] = max(min(m1[cb], m2[cb]), min(max(m1[cb], m2[cb]), kx)); m1[cb] = min(m1[cb], kx);     // v_med3_i32, v_min_i32
+                    }
                 }
             }
         }
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(64 * HM_WAVES, 4) void k_hamming_mfma(
     }
     // ---- the two lane halves saw disjoint trains of the same query: merge, add popc(query), write
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
+    for (int cb = 0; cb < HM_CB; cb++) {
         const int o1 = __shfl_xor(m1[cb], 32, 64), o2 = __shfl_xor(m2[cb], 32, 64);
         const int b1 = min(m1[cb], o1);
         const int b2 = min(max(m1[cb], o1), min(m2[cb], o2));
@@ -364,7 +388,7 @@ void match_launch_bf(hipStream_t s, const uint8_t* q, long long q_pair_bytes, co
 {
     if (variant == 3 && nt <= HM_MAX_NT) {
         const int q_blocks = (nq + HM_QW * HM_WAVES - 1) / (HM_QW * HM_WAVES);
-        hipLaunchKernelGGL(k_hamming_mfma, dim3(n_pairs * q_blocks), dim3(64 * HM_WAVES), 0, s, q, q_pair_bytes, t, t_pair_bytes, nq, nt, nq_n, nt_n,
+        hipLaunchKernelGGL(k_hamming_mfma, dim3(n_pairs * q_blocks), dim3(HM_TPB), 0, s, q, q_pair_bytes, t, t_pair_bytes, nq, nt, nq_n, nt_n,
                            q_blocks, bi, bd, sd);
         return;
     }

@@ -119,3 +119,39 @@ def test_full_batch_properties(ctx, oracle):
     par = oracle.default_params()
     for f in (0, 37, 101, 200, 255):
         _same(kps[f, :counts[f]], desc[f, :counts[f]], oracle.orb_extract(par, imgs[f]))
+
+
+@pytest.mark.parametrize("env", [{"CCM_ORB_FUSED": "0"}, {"CCM_FC_PACKED": "0"}, {"CCM_ORB_CHUNK": "2"}, {"CCM_BF_VARIANT": "0"}])
+def test_alternative_kernel_paths(env):
+    """The paths the defaults do not take -- two-kernel FAST through a score map (cells wider than one LDS tile), the
+    scalar rejection test, tiny upload chunks, the vector-ALU matcher (more than 2048 train rows) -- selected by their
+    environment switches in a child process (the switches are read once per process) and checked against the oracle."""
+    import subprocess, sys
+    code = r'''
+import numpy as np
+from motioncheck_ccm_slam_amd import _lib, synth
+from motioncheck_ccm_slam_amd.orb import ORBextractor
+from motioncheck_ccm_slam_amd.matcher import ORBmatcher
+from oracle import oracle_py as O
+ctx = _lib.Context(0)
+ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+imgs = synth.frames(20, 5)
+kps, desc, counts = ex.extract_batch(imgs)
+for f in range(5):
+    r = O.orb_extract(O.default_params(), imgs[f])
+    n = counts[f]
+    assert n == len(r["kps"]) and (desc[f, :n] == r["desc"]).all()
+    for name in r["kps"].dtype.names:
+        assert (kps[f, :n][name] == r["kps"][name]).all(), name
+noise = np.random.default_rng(0).integers(0, 256, (480, 752), dtype=np.uint8)
+k2, d2 = ex(noise); r = O.orb_extract(O.default_params(), noise)
+assert len(k2) == len(r["kps"]) and (d2 == r["desc"]).all()
+m = ORBmatcher(ctx=ctx)
+bi, bd, sd = m.BruteForce(desc[0, :counts[0]], desc[1, :counts[1]])
+rbi, rbd, rsd = O.hamming_match(desc[0, :counts[0]], desc[1, :counts[1]])
+assert (bi[0] == rbi).all() and (bd[0] == rbd).all() and (sd[0] == rsd).all()
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]

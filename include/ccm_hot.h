@@ -424,6 +424,10 @@ int ccm_ba_landmark_cuts(const int32_t* edge_point, int n_edges, int n_points, i
 #define CCM_COMM_ID_BYTES 128
 int ccm_comm_unique_id(uint8_t id[CCM_COMM_ID_BYTES]);
 int ccm_comm_init(ccm_ctx*, const uint8_t id[CCM_COMM_ID_BYTES], int n_ranks, int rank);
+/* Rehearsal transport for machines with ONE GPU: the ranks are processes of this host that exchange through the POSIX
+ * shared-memory segment `name` (rank 0 creates it; capacity_bytes per rank must hold the largest all-reduce: 36 doubles
+ * per reduced-camera block + 6 per keyframe).  Same data path as ccm_comm_init except for the all-reduce itself. */
+int ccm_comm_init_shm(ccm_ctx*, const char* name, int n_ranks, int rank, size_t capacity_bytes);
 int ccm_comm_destroy(ccm_ctx*);
 
 /* SE3Quat / Converter helpers (src/Converter.cc:40-56, 86-93): float32 4x4 row-major

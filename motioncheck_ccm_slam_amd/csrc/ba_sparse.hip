@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void k_pcg_cl_gather(const double* __restrict_
     const int rr = 6 * (br % PCG_CL) + r, cc = 6 * (bc % PCG_CL) + c;
     const double v = Hb[i];
     M[rr * PCG_CN + cc] = v;
-    M[cc * PCG_CN + rr] = v;            // upper block triangle stored once; a diagonal block writes its own mirror
+    if (br != bc) M[cc * PCG_CN + rr] = v;   // upper block triangle stored once; a diagonal block holds both of its halves
+                                             // (mirroring it too would race two not-quite-equal values into one slot)
 }
 // in-place inverse of every cluster matrix by Gauss-Jordan without pivoting (SPD); unused rows of the last cluster
 // are made identity; a non-positive pivot raises `bad`

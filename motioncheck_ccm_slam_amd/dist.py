@@ -74,3 +74,11 @@ def init_comm(ctx, rank: int, world: int):
         t = t.cpu()
     ident = t.numpy().astype(np.uint8)
     ctx.check(lib.ccm_comm_init(ctx.handle, _lib.ptr(ident), world, rank))
+
+
+def init_comm_shm(ctx, name: str, rank: int, world: int, capacity_bytes: int = 64 << 20):
+    """Rehearsal transport (one GPU, several processes): all-reduce through a POSIX shared-memory segment instead of
+    RCCL.  Everything else of the sharded solve is the production path."""
+    from . import _lib
+    lib = _lib.load()
+    ctx.check(lib.ccm_comm_init_shm(ctx.handle, name.encode(), int(world), int(rank), int(capacity_bytes)))

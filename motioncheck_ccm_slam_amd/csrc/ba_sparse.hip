@@ -249,9 +249,12 @@ __global__ __launch_bounds__(256) void k_pcg_cl_gather(const double* __restrict_
     double* M = Mc + (long long)(br / PCG_CL) * PCG_CN * PCG_CN;
     const int rr = 6 * (br % PCG_CL) + r, cc = 6 * (bc % PCG_CL) + c;
     const double v = Hb[i];
+    // The upper block triangle is stored once, so an off-diagonal block is mirrored.  Of a diagonal block only the upper
+    // half is used, mirrored as well: taking both halves would let two not-quite-equal values race into one slot (seen
+    // as 1e-15 run-to-run noise) and leave the preconditioner not exactly symmetric.
+    if (br == bc && r > c) return;
     M[rr * PCG_CN + cc] = v;
-    if (br != bc) M[cc * PCG_CN + rr] = v;   // upper block triangle stored once; a diagonal block holds both of its halves
-                                             // (mirroring it too would race two not-quite-equal values into one slot)
+    M[cc * PCG_CN + rr] = v;
 }
 // in-place inverse of every cluster matrix by Gauss-Jordan without pivoting (SPD); unused rows of the last cluster
 // are made identity; a non-positive pivot raises `bad`

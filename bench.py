@@ -55,13 +55,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal switches (a one-GPU box cannot host two RCCL ranks): CCM_BENCH_BACKEND=gloo moves the torch.distributed
+    # control traffic to gloo and lets several ranks share a GPU, CCM_BENCH_COMM=shm replaces the library's RCCL all-reduce
+    # by its shared-memory transport.  The driver's runs use neither.
+    backend = os.environ.get("CCM_BENCH_BACKEND", "nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
+    red_dev = "cuda" if backend == "nccl" else "cpu"          # where the few scalars that cross ranks live
 
     from motioncheck_ccm_slam_amd import _lib, synth
     from motioncheck_ccm_slam_amd import dist as D
@@ -103,10 +113,10 @@ def main():
     ctx.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        ft = torch.tensor([feats], dtype=torch.float64, device="cuda")
+        ft = torch.tensor([feats], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ft)
         feats_all = float(ft.item())
         dist.barrier()
@@ -182,7 +192,10 @@ def main():
             torch.cuda.set_device(local)                                # the current device is per thread
             from motioncheck_ccm_slam_amd.optimizer import Optimizer
             if world > 1:
-                D.init_comm(ctx, rank, world)
+                if os.environ.get("CCM_BENCH_COMM") == "shm":
+                    D.init_comm_shm(ctx, "/ccm_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world)
+                else:
+                    D.init_comm(ctx, rank, world)
             g = synth.gba_graph()
             Optimizer.MapFusionGBA(g, 1, ctx=ctx)                       # warm-up (rocSOLVER init, allocations)
             fence()
@@ -191,7 +204,7 @@ def main():
             call_s = time.perf_counter() - tg
             lm_s = r["t_linearize"] + r["t_schur"] + r["t_solve"] + r["t_update"]
             if world > 1:
-                t = torch.tensor([lm_s, call_s], dtype=torch.float64, device="cuda")
+                t = torch.tensor([lm_s, call_s], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 lm_s, call_s = float(t[0]), float(t[1])
             gba = {"metric": "GBA LM iterations/s (2000 KF, 200k points, %d edges)" % len(g["edge_pose"]),

@@ -48,7 +48,9 @@ __device__ __forceinline__ int wave_sum(int v)
 // Fixed-point bilinear exactly as cv::resize(INTER_LINEAR) for 8-bit data:
 // weights are the host-made 11-bit tables, horizontal pass int32, vertical pass
 // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.
-#define RS_ROWS 8
+#ifndef RS_ROWS
+#define RS_ROWS 8                // rows per thread (measured: 4 -> 0.186, 8 -> 0.172, 16 -> 0.260 ms)
+#endif
 __global__ __launch_bounds__(256) void k_pyr_resize(const OrbGeom g, int level)
 {
     const OrbLevel& D = g.lv[level];
@@ -741,7 +743,9 @@ __device__ __forceinline__ int oct_nonempty(const int* cc, int p)
     return (cc[4 * p] > 0) + (cc[4 * p + 1] > 0) + (cc[4 * p + 2] > 0) + (cc[4 * p + 3] > 0);
 }
 
-#define OCT_WAVES 4             // measured: 1 -> 0.22 ms, 4 -> 0.135 ms, 8 -> 0.23 ms per 256 frames
+#ifndef OCT_WAVES
+#define OCT_WAVES 4             // measured: 1 -> 0.22 ms, 2 -> 0.41, 4 -> 0.135, 8 -> 0.23 ms per 256 frames
+#endif
 __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, const OrbCell* __restrict__ cells,
                                                const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
                                                unsigned* keysA, unsigned* keysB,

@@ -402,8 +402,12 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 // the survivor list holds `surv_cap` pixels; the detection rows are processed in blocks of surv_cap / pitch rows
 // NMS works on the list of scored pixels (FC_NZ entries) and the list of local maxima (FC_KEPT); a band that overflows
 // either list takes the per-cell row scan instead.
+#ifndef FC_NZ
 #define FC_NZ 1024
+#endif
+#ifndef FC_KEPT
 #define FC_KEPT 512
+#endif
 #define FC_CELLS 32
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {

@@ -1,5 +1,5 @@
-// match_host.cpp -- C ABI of the matcher (include/ccm_hot.h): brute-force Hamming search and
-// ORBmatcher::SearchByBoW (cslam/src/ORBmatcher.cpp:178-306, 565-698).
+// match_host.cpp -- C ABI of the matcher (include/ccm_hot.h): brute-force Hamming search,
+// ORBmatcher::SearchByBoW (cslam/src/ORBmatcher.cpp:178-306, 565-698; on the device, k_bow_greedy) and the windowed matchers.
 #include "ccm_internal.h"
 #include <algorithm>
 #include <climits>
@@ -11,6 +11,17 @@ void match_launch_bf(hipStream_t, const uint8_t* q, long long q_pair_bytes, cons
                      unsigned* part_best, int* part_second, int* bi, int* bd, int* sd);
 void match_launch_ranges(hipStream_t, const uint8_t* d1, const uint8_t* d2, const int* order2, const int* start,
                          const int* len, const long long* off, int n1, unsigned short* dist);
+struct BowDev {                                  // must match match_kernels.hip
+    int n_groups, n1;
+    const int* ga; const int* gae; const int* gb; const int* gbe;
+    const int* ord1; const int* ord2;
+    const uint8_t* d1; const uint8_t* d2;
+    const uint8_t* valid1; const uint8_t* valid2;
+    const float* angle1; const float* angle2;
+    uint8_t* taken; int* match12; int* bin_of; int* hist;
+    float nnratio; int th, strict_th, check_ori;
+};
+void match_launch_bow(hipStream_t, const BowDev&);
 
 struct WindowBufs;
 void match_window_free(WindowBufs*);
@@ -19,11 +30,13 @@ struct MatchState {
     DevBuf q, t, nqn, ntn, bi, bd, sd;          // brute force staging
     DevBuf part_best, part_second;              // per-split partial results
     DevBuf d1, d2, order2, start, len, off, dist; // BoW staging
+    DevBuf order1, grp[4], bv1, bv2, ba1, ba2, taken, m12, binof, hist;   // device-side SearchByBoW
 };
 void match_state_free(MatchState* s)
 {
     if (!s) return;
-    DevBuf* all[] = { &s->q, &s->t, &s->nqn, &s->ntn, &s->bi, &s->bd, &s->sd, &s->d1, &s->d2, &s->order2, &s->start, &s->len, &s->off, &s->dist, &s->part_best, &s->part_second };
+    DevBuf* all[] = { &s->q, &s->t, &s->nqn, &s->ntn, &s->bi, &s->bd, &s->sd, &s->d1, &s->d2, &s->order2, &s->start, &s->len, &s->off, &s->dist, &s->part_best, &s->part_second,
+                      &s->order1, &s->grp[0], &s->grp[1], &s->grp[2], &s->grp[3], &s->bv1, &s->bv2, &s->ba1, &s->ba2, &s->taken, &s->m12, &s->binof, &s->hist };
     for (DevBuf* b : all) b->release();
     match_window_free(s->win);
     delete s;
@@ -193,55 +206,59 @@ int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, co
     for (int i = 0; i < n1; i++) match12[i] = -1;
     if (n1 == 0 || n2 == 0) return 0;
     CCM_HIP(c, hipSetDevice(c->device));
-    BowRanges R;
+    if (!c->match) c->match = new MatchState();
+    MatchState& M = *c->match;
+    // FeatureVector order: node ascending, feature index ascending inside a node (DBoW2 fills it so); the merge walk of
+    // :201-298 pairs the runs of equal node ids -- one group per common node
+    std::vector<int> ord1(n1), ord2(n2);
+    std::iota(ord1.begin(), ord1.end(), 0); std::iota(ord2.begin(), ord2.end(), 0);
+    auto by_node = [](const int32_t* node) { return [node](int a, int b) { return node[a] != node[b] ? node[a] < node[b] : a < b; }; };
+    std::stable_sort(ord1.begin(), ord1.end(), by_node(node1));
+    std::stable_sort(ord2.begin(), ord2.end(), by_node(node2));
+    std::vector<int> grp[4];
     {
-        int rc = bow_ranges(c, desc1, node1, valid1, n1, desc2, node2, n2, R);
-        if (rc) return rc;
+        size_t pa = 0, pb = 0;
+        while (pa < ord1.size() && pb < ord2.size()) {
+            const int na = node1[ord1[pa]], nb2 = node2[ord2[pb]];
+            if (na < 0) { pa++; continue; }                              // features without a node are in no FeatureVector entry
+            if (nb2 < 0) { pb++; continue; }
+            if (na < nb2) { while (pa < ord1.size() && node1[ord1[pa]] == na) pa++; continue; }
+            if (nb2 < na) { while (pb < ord2.size() && node2[ord2[pb]] == nb2) pb++; continue; }
+            size_t ae = pa, be = pb;
+            while (ae < ord1.size() && node1[ord1[ae]] == na) ae++;
+            while (be < ord2.size() && node2[ord2[be]] == na) be++;
+            grp[0].push_back((int)pa); grp[1].push_back((int)ae); grp[2].push_back((int)pb); grp[3].push_back((int)be);
+            pa = ae; pb = be;
+        }
     }
-    const std::vector<int>&ord1 = R.ord1, &ord2 = R.ord2, &start = R.start, &len = R.len;
-    const std::vector<long long>& off = R.off;
-    const std::vector<unsigned short>& dist = R.dist;
-    // greedy acceptance in the reference's visiting order (sequential by construction: a side-2
-    // feature matched earlier is skipped later, ORBmatcher.cpp:228-229 / :619)
-    const int HISTO = 30;
-    std::vector<int> rot[HISTO];
-    const float factor = 1.0f / HISTO;
-    std::vector<uint8_t> taken(n2, 0);
+    const int ng = (int)grp[0].size();
+    hipStream_t st = c->stream;
+    auto up = [&](DevBuf& bf, const void* src, size_t bytes) -> int {
+        CCM_RESERVE(c, bf, std::max<size_t>(bytes, 16));
+        if (bytes) CCM_HIP(c, hipMemcpyAsync(bf.p, src, bytes, hipMemcpyHostToDevice, st));
+        return CCM_OK;
+    };
+    int rc;
+    if ((rc = up(M.d1, desc1, (size_t)n1 * 32)) || (rc = up(M.d2, desc2, (size_t)n2 * 32))) return rc;
+    if ((rc = up(M.order1, ord1.data(), (size_t)n1 * 4)) || (rc = up(M.order2, ord2.data(), (size_t)n2 * 4))) return rc;
+    for (int k = 0; k < 4; k++) if ((rc = up(M.grp[k], grp[k].data(), (size_t)ng * 4))) return rc;
+    if ((rc = up(M.bv1, valid1, (size_t)n1))) return rc;
+    if (valid2 && (rc = up(M.bv2, valid2, (size_t)n2))) return rc;
+    if (o->check_ori && ((rc = up(M.ba1, angle1, (size_t)n1 * 4)) || (rc = up(M.ba2, angle2, (size_t)n2 * 4)))) return rc;
+    CCM_RESERVE(c, M.taken, (size_t)n2); CCM_RESERVE(c, M.m12, (size_t)n1 * 4); CCM_RESERVE(c, M.binof, (size_t)n1 * 4); CCM_RESERVE(c, M.hist, 32 * 4);
+    CCM_HIP(c, hipMemsetAsync(M.taken.p, 0, (size_t)n2, st));
+    CCM_HIP(c, hipMemsetAsync(M.m12.p, 0xFF, (size_t)n1 * 4, st));
+    CCM_HIP(c, hipMemsetAsync(M.hist.p, 0, 32 * 4, st));
+    BowDev B{ ng, n1, M.grp[0].as<int>(), M.grp[1].as<int>(), M.grp[2].as<int>(), M.grp[3].as<int>(), M.order1.as<int>(), M.order2.as<int>(),
+              M.d1.as<uint8_t>(), M.d2.as<uint8_t>(), M.bv1.as<uint8_t>(), valid2 ? M.bv2.as<uint8_t>() : nullptr,
+              M.ba1.as<float>(), M.ba2.as<float>(), M.taken.as<uint8_t>(), M.m12.as<int>(), M.binof.as<int>(), M.hist.as<int>(),
+              o->nnratio, o->th, o->strict_th, o->check_ori };
+    match_launch_bow(st, B);
+    CCM_HIP(c, hipGetLastError());
     int nmatches = 0;
-    for (int a = 0; a < n1; a++) {
-        const int i1 = ord1[a];
-        if (node1[i1] < 0 || !valid1[i1] || len[i1] == 0) continue;
-        int bd1 = 256, bi = -1, bd2 = 256;
-        const unsigned short* d = dist.data() + off[i1];
-        for (int k = 0; k < len[i1]; k++) {
-            const int i2 = ord2[start[i1] + k];
-            if (taken[i2]) continue;
-            if (valid2 && !valid2[i2]) continue;
-            const int dd = d[k];
-            if (dd < bd1) { bd2 = bd1; bd1 = dd; bi = i2; }
-            else if (dd < bd2) bd2 = dd;
-        }
-        if (ccm_ratio_test(bd1, bd2, o->nnratio, o->th, o->strict_th)) {
-            match12[i1] = bi;
-            taken[bi] = 1;
-            if (o->check_ori) {
-                float r = angle1[i1] - angle2[bi];
-                if (r < 0.0) r += 360.0f;
-                int bin = (int)std::round(r * factor);      // 1/HISTO_LENGTH as in the reference: bins 0..12
-                if (bin == HISTO) bin = 0;
-                rot[bin].push_back(i1);
-            }
-            nmatches++;
-        }
-    }
-    if (o->check_ori) {
-        int i1, i2, i3;
-        three_maxima(rot, HISTO, i1, i2, i3);
-        for (int i = 0; i < HISTO; i++) {
-            if (i == i1 || i == i2 || i == i3) continue;
-            for (int idx : rot[i]) { match12[idx] = -1; nmatches--; }
-        }
-    }
+    CCM_HIP(c, hipMemcpyAsync(match12, M.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+    CCM_HIP(c, hipMemcpyAsync(&nmatches, M.hist.as<int>() + 30, 4, hipMemcpyDeviceToHost, st));
+    CCM_HIP(c, hipStreamSynchronize(st));
     return nmatches;
 }
 

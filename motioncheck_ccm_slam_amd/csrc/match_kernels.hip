@@ -316,6 +316,112 @@ __global__ __launch_bounds__(256) void k_hamming_ranges(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW on the device (cslam/src/ORBmatcher.cpp:178-306 and :565-698).  A side-2 feature belongs to
+// exactly one vocabulary node, so the reference's sequential "already matched" bookkeeping only couples features of the
+// SAME node: one wave per node group walks its side-1 features in order (the reference's order), lanes scan the node's
+// side-2 features, and the wave keeps (best, second) exactly as the if / else-if of :233-245 does -- best = first
+// minimal distance in scan order, second = second smallest including duplicates.  Accepted matches mark their side-2
+// feature taken, vote in the rotation histogram (integer counts), and k_bow_filter applies ComputeThreeMaxima
+// (:1607-1648) and drops the matches of the other bins (:271-289).
+struct BowDev {
+    int n_groups, n1;
+    const int* ga; const int* gae; const int* gb; const int* gbe;     // per group: ranges in ord1 / ord2
+    const int* ord1; const int* ord2;
+    const uint8_t* d1b; const uint8_t* d2b;                           // descriptors, 16-byte aligned
+    const uint8_t* valid1; const uint8_t* valid2;                     // valid2 may be null
+    const float* angle1; const float* angle2;
+    uint8_t* taken; int* match12; int* bin_of; int* hist;             // hist[30] + [30] = kept count
+    float nnratio; int th, strict_th, check_ori;
+};
+__global__ __launch_bounds__(256) void k_bow_greedy(BowDev B)
+{
+    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (grp >= B.n_groups) return;
+    const int a0 = B.ga[grp], a1 = B.gae[grp], b0 = B.gb[grp], b1 = B.gbe[grp];
+    for (int a = a0; a < a1; a++) {
+        const int i1 = B.ord1[a];
+        if (!B.valid1[i1]) continue;                                 // wave-uniform
+        const uint4* D1 = reinterpret_cast<const uint4*>(B.d1b); const uint4* D2 = reinterpret_cast<const uint4*>(B.d2b);
+        const uint4 q0 = D1[2 * (long long)i1], q1 = D1[2 * (long long)i1 + 1];
+        int bd1 = 256, bd2 = 256, bi = -1;
+        for (int base = b0; base < b1; base += 64) {
+            const int j = base + lane;
+            int d = 1 << 20, i2 = -1;                                // lanes without a candidate never win
+            if (j < b1) {
+                i2 = B.ord2[j];
+                if (!B.taken[i2] && (!B.valid2 || B.valid2[i2])) d = ham256(q0, q1, D2[2 * (long long)i2], D2[2 * (long long)i2 + 1]);
+            }
+            // chunk best = first minimal distance in lane (= scan) order; chunk second = smallest of the other lanes
+            unsigned key = ((unsigned)d << 6) | (unsigned)lane;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, s, 64));
+            const int cb = (int)(key >> 6), cl = (int)(key & 63u);
+            int o = lane == cl ? (1 << 20) : d;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) o = min(o, __shfl_xor(o, s, 64));
+            const int ci2 = __shfl(i2, cl, 64);
+            // fold the chunk into the running pair the way the sequential if / else-if would
+            if (cb < bd1) { bd2 = min(bd1, o); bd1 = cb; bi = ci2; }
+            else bd2 = min(bd2, cb);
+        }
+        const bool pass = B.strict_th ? (bd1 < B.th) : (bd1 <= B.th);
+        if (bi >= 0 && pass && (float)bd1 < B.nnratio * (float)bd2) {
+            if (lane == 0) {
+                B.match12[i1] = bi;
+                B.taken[bi] = 1;
+                if (B.check_ori) {
+                    float r = B.angle1[i1] - B.angle2[bi];
+                    if (r < 0.0) r += 360.0f;
+                    int bin = (int)roundf(r * (1.0f / 30));          // 1/HISTO_LENGTH as in the reference (:191, :260)
+                    if (bin == 30) bin = 0;
+                    B.bin_of[i1] = bin;
+                    atomicAdd(&B.hist[bin], 1);
+                }
+            }
+            __threadfence_block();                                   // the taken flag is read by this wave's next feature
+        }
+    }
+}
+// one workgroup: ComputeThreeMaxima on the 30 bin counts, then every match outside the kept bins is dropped
+__global__ __launch_bounds__(256) void k_bow_filter(BowDev B)
+{
+    __shared__ int keep[3];
+    __shared__ int cnt;
+    if (threadIdx.x == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        if (B.check_ori) {
+            for (int i = 0; i < 30; i++) {
+                const int s = B.hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) ind3 = -1;
+        }
+        keep[0] = ind1; keep[1] = ind2; keep[2] = ind3; cnt = 0;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < B.n1; i += 256) {
+        if (B.match12[i] < 0) continue;
+        if (B.check_ori) {
+            const int b = B.bin_of[i];
+            if (b != keep[0] && b != keep[1] && b != keep[2]) { B.match12[i] = -1; continue; }
+        }
+        mine++;
+    }
+    atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) B.hist[30] = cnt;
+}
+void match_launch_bow(hipStream_t s, const BowDev& B)
+{
+    if (B.n_groups > 0) hipLaunchKernelGGL(k_bow_greedy, dim3((B.n_groups + 3) / 4), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_bow_filter, dim3(1), dim3(256), 0, s, B);
+}
+
 // Frame::GetFeaturesInArea (src/Frame.cpp:200-253) + the DescriptorDistance calls of the windowed matchers
 // (SearchByProjection / Fuse / SearchBySim3 ..., cslam/src/ORBmatcher.cpp:71-148 and following): one wave per
 // query walks the grid cells of its window in the reference's order (ix outer, iy inner, cell content in

@@ -51,7 +51,11 @@ int ccm_comm_init(ccm_ctx* c, const uint8_t id[CCM_COMM_ID_BYTES], int n_ranks, 
     comm_state_free(c);
     c->comm = new CommState();
     c->comm->n_ranks = n_ranks; c->comm->rank = rank;
-    if (n_ranks == 1) return CCM_OK;
+    // A one-rank job needs no communicator.  CCM_COMM_RCCL_SINGLE=1 creates one all the same, so that the RCCL
+    // calls of the sharded path (ncclCommInitRank, in-place ncclAllReduce on the context's stream) can be run on a
+    // machine with one GPU (tests/test_ba_gpu.py).
+    const char* single = getenv("CCM_COMM_RCCL_SINGLE");
+    if (n_ranks == 1 && !(single && single[0] == '1')) return CCM_OK;
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
     ncclResult_t r = ncclCommInitRank(&c->comm->comm, n_ranks, u, rank);
@@ -149,7 +153,7 @@ static int shm_allreduce(ccm_ctx* c, T* dev, size_t n, Op op)
 
 int comm_allreduce_f64(ccm_ctx* c, double* dev, size_t n, bool max_op)
 {
-    if (!c->comm || c->comm->n_ranks == 1) return CCM_OK;
+    if (!c->comm || (c->comm->n_ranks == 1 && !c->comm->comm)) return CCM_OK;
     if (c->comm->shm)
         return max_op ? shm_allreduce(c, dev, n, [](double a, double b) { return a > b ? a : b; })
                       : shm_allreduce(c, dev, n, [](double a, double b) { return a + b; });
@@ -159,7 +163,7 @@ int comm_allreduce_f64(ccm_ctx* c, double* dev, size_t n, bool max_op)
 }
 int comm_allreduce_u8_max(ccm_ctx* c, uint8_t* dev, size_t n)
 {
-    if (!c->comm || c->comm->n_ranks == 1) return CCM_OK;
+    if (!c->comm || (c->comm->n_ranks == 1 && !c->comm->comm)) return CCM_OK;
     if (c->comm->shm) return shm_allreduce(c, dev, n, [](uint8_t a, uint8_t b) { return a > b ? a : b; });
     ncclResult_t r = ncclAllReduce(dev, dev, n, ncclUint8, ncclMax, c->comm->comm, c->stream);
     if (r != ncclSuccess) return ccm_fail(c, CCM_E_COMM, "ncclAllReduce: %s", ncclGetErrorString(r));

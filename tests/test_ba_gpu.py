@@ -171,3 +171,30 @@ print("ok")
     else:
         assert np.abs(a["poses"] - b["poses"]).max() < 1e-12 and np.abs(a["points"] - b["points"]).max() < 1e-12
     assert int(a["pairs"]) > 0 and int(b["pairs"]) > 0 and int(a["pairs"]) != int(b["pairs"])      # each rank enumerated its own share
+
+
+def test_rccl_calls_with_one_rank_communicator():
+    """The RCCL leg itself (ncclGetUniqueId, ncclCommInitRank, in-place ncclAllReduce f64 sum/max and u8 max on the
+    context's stream) with a communicator of ONE rank, in a process that has torch loaded like bench.py: the reduced
+    system goes through RCCL and the result must equal the solve without a communicator, bit for bit."""
+    import subprocess, sys
+    code = r'''
+import numpy as np, torch
+torch.cuda.init()
+from motioncheck_ccm_slam_amd import _lib, synth, dist
+from motioncheck_ccm_slam_amd.optimizer import Optimizer
+g = synth.gba_graph(n_kf=240, n_points=20000, n_agents=3, seed=240)
+ctx0 = _lib.Context(0)
+r0 = Optimizer.MapFusionGBA(g, 3, ctx=ctx0)
+ctx = _lib.Context(0)
+dist.init_comm(ctx, 0, 1)
+r = Optimizer.MapFusionGBA(g, 3, ctx=ctx)
+assert (r["poses"] == r0["poses"]).all() and (r["points"] == r0["points"]).all()
+assert r["iterations_done"] == r0["iterations_done"] and r["chi2_final"] == r0["chi2_final"]
+ctx.close(); ctx0.close()
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, CCM_BA_DENSE_MAX="0", CCM_COMM_RCCL_SINGLE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]

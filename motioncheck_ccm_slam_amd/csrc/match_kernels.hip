@@ -104,16 +104,18 @@ __global__ __launch_bounds__(THREADS) void k_hamming_bf(
 // k_hamming_mfma: the same best / second-best search on the matrix cores.
 //   hamming(a, b) = popc(a) + popc(b) - 2 <a, b>   with <a, b> the dot product of the 0/1 bit vectors,
 // so a 32 x 32 block of distances is eight v_mfma_i32_32x32x32_i8 (K = 256 bits) on operands whose bits are
-// expanded to bytes: train rows to 0/1, query columns to 0/-1, which leaves -<a, b> in the accumulator.
+// expanded to bytes: train rows to 0/32, query columns to 0/-128, so that a common bit adds -4096 = -(2 << 11).
 // Layout: A operand = 32 train rows, B operand = 32 query columns.  C/D puts column j = lane & 31 on the lane and
 // rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) in its 16 registers, i.e. a lane sees ONE query and 16 trains per
-// tile, so the running (best, second) of that query are two registers per lane.  The running state is the signed key
-//   ((popc(b) - 2 <a, b>) << 16) + train index = (acc << 17) + w[row]      (one v_lshl_add_u32)
-// -- popc(a) is constant per lane and added at the end -- folded with  second = med3(best, second, key);
-// best = min(best, key): three VALU instructions per distance instead of ~18, the rest is MFMA.
+// tile, so the running (best, second) of that query are two registers per lane.  The accumulator of the first k-step
+// is preloaded (C operand) with the row word ((popc(train) + HM_BIAS) << 11) | train index, so the matrix cores
+// deliver the finished signed key
+//   ((popc(train) - 2 <a, b> + HM_BIAS) << 11) | train index
+// -- popc(query) is constant per lane and added at the end -- and the fold is  second = med3(best, second, key);
+// best = min(best, key): two VALU instructions per distance instead of ~18, the rest is MFMA.
 // A/B fragments: lane (h = lane >> 5, r = lane & 31) supplies the 16 bytes of k-step s from bits [32 s + 16 h,
 // 32 s + 16 h + 16) of its row / column; A and B use the same k assignment, which is all the dot product needs.
-// One workgroup = 4 waves x 64 queries; the 0/1 train fragments of a 32-train tile (8 KiB) are expanded once per
+// One workgroup = 4 waves x 64 queries; the train fragments of a 32-train tile (8 KiB) are expanded once per
 // workgroup into LDS (double-buffered) and read back as ds_read_b128.
 typedef int hm_v4i __attribute__((ext_vector_type(4)));
 typedef int hm_v16i __attribute__((ext_vector_type(16)));
@@ -124,31 +126,45 @@ typedef int hm_v16i __attribute__((ext_vector_type(16)));
 #ifndef HM_WAVES
 #define HM_WAVES 4
 #endif
+#ifndef HM_WG_PER_CU
+#define HM_WG_PER_CU 4           // measured at 10 k pairs: 4 -> 2.32 ms, 3 -> 2.48 ms
+#endif
 #define HM_QW (32 * HM_CB)       // queries per wave
 #define HM_TPB (64 * HM_WAVES)
-#define HM_SENT 0x3FFFFFFF       // key of "no train": larger than every real key, index field 0xFFFF
+#define HM_SENT 0x3FFFFFFF       // key of "no train": larger than every real key
 #define HM_MAX_NT 2048           // train rows whose row words fit the LDS table (the launcher falls back beyond)
 
-__device__ __forceinline__ hm_v4i hm_expand16(unsigned hw, unsigned mul)
+// median of three keys.  The compiler has no integer med3 pattern for variables, but every key is a positive normal
+// float when read as one -- (hamming - popc(query) + HM_BIAS) << 11 | index with the distance field in [4096, 4864],
+// HM_SENT = 0x3FFFFFFF -- and positive floats order like their bit patterns, so v_med3_f32 returns the same register.
+#define HM_BIAS 4352
+#define HM_IDX_BITS 11           // train index field of a key (HM_MAX_NT = 2048 rows)
+__device__ __forceinline__ int hm_med3(int a, int b, int c)
 {
-    // 4 bits -> 4 bytes: n * 0x204081 puts bit i at bit 8 i; mul = 1 gives 0/1 bytes, mul = 255 gives 0/0xFF (-1)
+    return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(a), __int_as_float(b), __int_as_float(c)));
+}
+
+__device__ __forceinline__ hm_v4i hm_expand16(unsigned hw, int shift)
+{
+    // 4 bits -> 4 bytes: n * 0x204081 puts bit i at bit 8 i (the 24-bit multiply is exact, n < 16); the 0/1 bytes are
+    // then shifted to 0/32 (trains, shift 5) or 0/0x80 = -128 (queries, shift 7): a common bit contributes
+    // 32 * -128 = -2 << HM_IDX_BITS to the accumulator, i.e. -2 in the distance field of the key
+    // (the shift is applied to the nibble, not to the product: v_mul_u32_u24 stays a full-rate instruction)
     hm_v4i v;
-    // (x << 8) - x = 255 x without a 32-bit multiply; the 24-bit multiply is exact (n < 16)
-    unsigned b0 = __umul24((hw >> 0) & 15u, 0x204081u) & 0x01010101u, b1 = __umul24((hw >> 4) & 15u, 0x204081u) & 0x01010101u;
-    unsigned b2 = __umul24((hw >> 8) & 15u, 0x204081u) & 0x01010101u, b3 = __umul24((hw >> 12) & 15u, 0x204081u) & 0x01010101u;
-    if (mul == 255u) { b0 = (b0 << 8) - b0; b1 = (b1 << 8) - b1; b2 = (b2 << 8) - b2; b3 = (b3 << 8) - b3; }
-    v.x = (int)b0; v.y = (int)b1; v.z = (int)b2; v.w = (int)b3;
+    const unsigned hs = hw << shift, nm = 15u << shift, bm = 0x01010101u << shift;
+    v.x = (int)(__umul24(hs & nm, 0x204081u) & bm); v.y = (int)(__umul24((hs >> 4) & nm, 0x204081u) & bm);
+    v.z = (int)(__umul24((hs >> 8) & nm, 0x204081u) & bm); v.w = (int)(__umul24((hs >> 12) & nm, 0x204081u) & bm);
     return v;
 }
 
 // 4 workgroups per CU (<= 128 registers per lane): 255 pairs x 4 live query blocks = 1020 workgroups fit in ONE round
-__global__ __launch_bounds__(HM_TPB, 1024 / HM_TPB) void k_hamming_mfma(
+__global__ __launch_bounds__(HM_TPB, HM_WG_PER_CU * HM_TPB / 256) void k_hamming_mfma(
     const uint8_t* __restrict__ q, long long q_pair_bytes, const uint8_t* __restrict__ t, long long t_pair_bytes,
     int nq, int nt, const int* __restrict__ nq_n, const int* __restrict__ nt_n, int q_blocks,
     int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_dist)
 {
     __shared__ hm_v4i frag[2][8][64];          // [buffer][k-step][lane]: 16 expanded bytes
-    __shared__ __attribute__((aligned(16))) int wall[HM_MAX_NT];   // per train: (popc << 16) | index, HM_SENT past the live count
+    __shared__ __attribute__((aligned(16))) int wall[HM_MAX_NT];   // per train: (popc + HM_BIAS) << 11 | index, HM_SENT past the live count
     const int pair = blockIdx.x / q_blocks, qblk = blockIdx.x - pair * q_blocks;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, r = lane & 31;
     const int nqp = nq_n ? min(max(nq_n[pair], 0), nq) : nq;
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(HM_TPB, 1024 / HM_TPB) void k_hamming_mfma(
         for (int s = 0; s < 8; s++) { d[s] = qi < nqp ? qp[8 * (long long)qi + s] : 0u; pc += __popc(d[s]); }
         pa[cb] = pc;
 #pragma unroll
-        for (int s = 0; s < 8; s++) bq[cb][s] = hm_expand16((d[s] >> (16 * h)) & 0xFFFFu, 255u);
+        for (int s = 0; s < 8; s++) bq[cb][s] = hm_expand16((d[s] >> (16 * h)) & 0xFFFFu, 7);
     }
     int m1[HM_CB], m2[HM_CB];
 #pragma unroll
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(HM_TPB, 1024 / HM_TPB) void k_hamming_mfma(
 #pragma unroll
         for (int j = 0; j < HM_FPT; j++) {
             const int fi = tid + j * HM_TPB;
-            if (fi < 512) frag[buf][(fi >> 5) & 7][32 * (fi >> 8) + (fi & 31)] = hm_expand16((x.v[j] >> (16 * (fi >> 8))) & 0xFFFFu, 1u);
+            if (fi < 512) frag[buf][(fi >> 5) & 7][32 * (fi >> 8) + (fi & 31)] = hm_expand16((x.v[j] >> (16 * (fi >> 8))) & 0xFFFFu, 5);
         }
     };
     // row words of all trains, once per workgroup
@@ -213,12 +229,39 @@ __global__ __launch_bounds__(HM_TPB, 1024 / HM_TPB) void k_hamming_mfma(
             const uint4* d = reinterpret_cast<const uint4*>(tp + 8 * (long long)tr);
             const uint4 d0 = d[0], d1 = d[1];
             const int pb = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
-            w = (pb << 16) | tr;
+            w = ((pb + HM_BIAS) << HM_IDX_BITS) | tr;
         }
         wall[tr] = w;
     }
     const int ntiles = (ntp + 31) >> 5;
     const bool wave_live = q0 < nqp;                                    // waves past the live queries only help staging
+    // the sixteen matrix instructions of one tile into `acc`.  The accumulators start from the row words of the tile
+    // (C operand of the first k-step: row = train, the same word in every query column), so what comes out IS the key
+    //   ((popc(train) + HM_BIAS) << 11 | train) - (2 << 11) <train, query>.
+    auto mma = [&](int tile, int buf, hm_v16i (&acc)[HM_CB]) {
+        hm_v16i wc;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const hm_v4i w4 = *reinterpret_cast<const hm_v4i*>(&wall[32 * tile + 8 * g + 4 * h]);
+            wc[4 * g] = w4.x; wc[4 * g + 1] = w4.y; wc[4 * g + 2] = w4.z; wc[4 * g + 3] = w4.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const hm_v4i a = frag[buf][s][lane];
+#pragma unroll
+            for (int cb = 0; cb < HM_CB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[cb][s], s == 0 ? wc : acc[cb], 0, 0, 0);
+        }
+    };
+    // (best, second) of the lane's query folded over the 16 keys it sees in `acc`: v_med3_f32 + v_min_i32 per key
+    auto fold = [&](const hm_v16i (&acc)[HM_CB]) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+#pragma unroll
+            for (int cb = 0; cb < HM_CB; cb++) {
+                const int kx = acc[cb][i];
+                m2[cb] = hm_med3(m1[cb], m2[cb], kx); m1[cb] = min(m1[cb], kx);
+            }
+    };
     Raw nxt = fetch(0);
     if (ntiles > 0) stage(nxt, 0);
     nxt = fetch(1);
@@ -229,26 +272,8 @@ __global__ __launch_bounds__(HM_TPB, 1024 / HM_TPB) void k_hamming_mfma(
         if (tile + 2 < ntiles) nxt = fetch(tile + 2);
         if (wave_live) {
             hm_v16i acc[HM_CB];
-#pragma unroll
-            for (int cb = 0; cb < HM_CB; cb++) acc[cb] = hm_v16i{};
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const hm_v4i a = frag[buf][s][lane];
-#pragma unroll
-                for (int cb = 0; cb < HM_CB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[cb][s], acc[cb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const hm_v4i w4 = *reinterpret_cast<const hm_v4i*>(&wall[32 * tile + 8 * g + 4 * h]);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-#pragma unroll
-                    for (int cb = 0; cb < HM_CB; cb++) {
-                        const int kx = (int)(((unsigned)acc[cb][4 * g + e] << 17) + (unsigned)w4[e]);
-                        m2[cb] = max(min(m1[cb], m2[cb]), min(max(m1[cb], m2[cb]), kx)); m1[cb] = min(m1[cb], kx);     // v_med3_i32, v_min_i32
-                    }
-                }
-            }
+            mma(tile, buf, acc);
+            fold(acc);
         }
         __syncthreads();
     }
@@ -262,11 +287,11 @@ __global__ __launch_bounds__(HM_TPB, 1024 / HM_TPB) void k_hamming_mfma(
         if (h == 0 && qi < nq) {
             const long long o = (long long)pair * nq + qi;
             const bool live = qi < nqp;
-            const bool has1 = live && (b1 & 0xFFFF) != 0xFFFF, has2 = live && (b2 & 0xFFFF) != 0xFFFF;
-            const int bd = has1 ? (b1 >> 16) + pa[cb] : 256;
-            best_idx[o] = bd < 256 ? (b1 & 0xFFFF) : -1;           // the reference starts at 256 and compares with <
+            const bool has1 = live && b1 < HM_SENT, has2 = live && b2 < HM_SENT;
+            const int bd = has1 ? (b1 >> HM_IDX_BITS) - HM_BIAS + pa[cb] : 256;
+            best_idx[o] = bd < 256 ? (b1 & ((1 << HM_IDX_BITS) - 1)) : -1;           // the reference starts at 256 and compares with <
             best_dist[o] = bd;
-            second_dist[o] = has2 ? (b2 >> 16) + pa[cb] : 256;
+            second_dist[o] = has2 ? (b2 >> HM_IDX_BITS) - HM_BIAS + pa[cb] : 256;
         }
     }
 }

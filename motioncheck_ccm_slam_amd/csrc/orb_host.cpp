@@ -234,10 +234,10 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
         band.pitch = (short)pitch; band.bh = c0.ch;
         for (size_t k = a; k < b; k++) if (S.cells[k].ch != c0.ch) S.fused = false;      // cannot happen: one row, one height
         S.surv_cap = std::max(S.surv_cap, pitch);                 // at least one row per block
-        S.band_lds = std::max(S.band_lds, orb_fast_cells_lds(pitch, c0.ch, std::max(scap, pitch)));
         S.bands.push_back(band);
         a = b;
     }
+    for (const OrbBand& b : S.bands) S.band_lds = std::max(S.band_lds, orb_fast_cells_lds(b.pitch, b.bh, S.surv_cap));
     for (const OrbBand& b : S.bands) if (b.pitch > 256) S.fused = false;    // a single cell wider than the tile: two-kernel path
     if (S.band_lds > 60 * 1024) S.fused = false;                 // very large cells: keep the two-kernel path
     G.ncells = (int)S.cells.size(); G.ntiles = tile_acc;

@@ -409,17 +409,25 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 #define FC_KEPT 512
 #endif
 #define FC_CELLS 32
+#ifndef FC_TPB
+#define FC_TPB 256              // threads per band workgroup (measured: 192 0.56, 256 0.52, 320 0.75, 384 0.82 ms)
+#endif
+// Survivors are appended per wave to the wave's own segment of the list (running count in a scalar register, no
+// atomic): a row block has at most surv_cap / 4 items of 4 pixels, a wave takes every (FC_TPB / 64)-th run of 64
+// items, so its segment never needs more than this many entries.
+__host__ __device__ inline int fc_wave_cap(int surv_cap) { return ((surv_cap / 4 + FC_TPB - 1) / FC_TPB) * 256; }
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {
-    return 2 * (size_t)pitch * bh + (size_t)surv_cap * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 12 + 64;
+    return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 12 + 64 * 8;
 }
 
 
 // PACKED: the rejection test on two pixels per register with the packed 16-bit VALU (v_pk_sub_u16 / v_pk_max_u16 /
 // v_pk_min_u16): |v - n| <= t  <=>  (u16)(v + t - n) <= 2t.
-#ifndef FC_TPB
-#define FC_TPB 256              // threads per band workgroup (measured: 192 0.56, 256 0.52, 320 0.75, 384 0.82 ms)
-#endif
+__device__ __forceinline__ int fc_mbcnt(unsigned long long m, int base)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
+}
 template <bool PACKED>
 __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
                                                     unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl)
@@ -431,15 +439,17 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
     const int P = B.pitch, bh = B.bh, PW = P >> 2;
     uint8_t* T = fc_smem;                                   // pixels  [bh][P]
     uint8_t* S = fc_smem + (size_t)P * bh;                  // scores  [bh][P]
-    unsigned short* surv = reinterpret_cast<unsigned short*>(S + (size_t)P * bh);
-    int* nsurv = reinterpret_cast<int*>(surv + FC_SURV);     // [0] survivors of the row block, [1] scored pixels, [2] local maxima
+    constexpr int NW = FC_TPB / 64;
+    const int WCAP = fc_wave_cap(FC_SURV);
+    unsigned short* surv = reinterpret_cast<unsigned short*>(S + (size_t)P * bh);     // [NW][WCAP]
+    int* nsurv = reinterpret_cast<int*>(surv + NW * WCAP);   // [1] scored pixels, [2] local maxima, [4 + w] survivors of wave w in the row block
     unsigned short* nz = reinterpret_cast<unsigned short*>(nsurv + 8);
     unsigned* kept = reinterpret_cast<unsigned*>(nz + FC_NZ);
     int* cell_hi = reinterpret_cast<int*>(kept + FC_KEPT);   // per cell: local maxima with score >= iniThFAST
     int* cell_n = cell_hi + FC_CELLS;                        // per cell: keypoints written
     short* clo = reinterpret_cast<short*>(cell_n + FC_CELLS); // per cell: first detection column of the tile, and its width
     short* cwd = clo + FC_CELLS;
-    uint8_t* colmask = reinterpret_cast<uint8_t*>(cwd + FC_CELLS);   // per tile dword: which of its 4 pixels are detection columns
+    uint2* colmask = reinterpret_cast<uint2*>(cwd + FC_CELLS);       // per tile dword: 16-bit lane masks of its detection columns: .x pixels 0 and 2, .y pixels 1 and 3
     if (tid < FC_CELLS) {
         cell_hi[tid] = 0; cell_n[tid] = 0;
         if (tid < B.ncells) {
@@ -501,15 +511,15 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
     const int dw_lo = max(1, c_lo >> 2);
     const int dw_hi = min(PW - 2, (c_hi - 1) >> 2);
     if (tid < PW) {
-        unsigned mk = 0;
-        for (int i = 0; i < 4; i++) if (4 * tid + i >= c_lo && 4 * tid + i < c_hi) mk |= 1u << i;
-        colmask[tid] = (uint8_t)mk;
+        unsigned mk[4];
+        for (int i = 0; i < 4; i++) mk[i] = (4 * tid + i >= c_lo && 4 * tid + i < c_hi) ? 0xFFFFu : 0u;
+        colmask[tid] = make_uint2(mk[0] | (mk[2] << 16), mk[1] | (mk[3] << 16));
     }
     __syncthreads();
     if (abl == 1) return;                                    // staging only
+    unsigned short* wsurv = surv + wv * WCAP;
     for (int r0 = 3; r0 < bh - 3; r0 += RB) {
-        if (tid == 0) *nsurv = 0;
-        __syncthreads();
+        int wcnt = 0;                                          // survivors this wave has appended (wave-uniform)
         const int r1 = min(r0 + RB, bh - 3);
         const int items = (r1 - r0) * PW;
         for (int it0 = 0; it0 < items; it0 += FC_TPB) {           // uniform trip count: the ballots below need whole waves
@@ -517,7 +527,8 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
             const int rr = (int)(((unsigned)it * pw_inv) >> 20);
             const int row = r0 + rr, dw = it - rr * PW;
             const int px = 4 * dw;
-            unsigned keep4 = 0;
+            unsigned keep4 = 0;                                 // scalar path: bit i = pixel i survives
+            unsigned kk0 = 0, kk1 = 0;                          // packed path: 16-bit halves, .lo/.hi of kk0 = pixels 0 / 2, of kk1 = pixels 1 / 3
             if (!PACKED && it < items && px + 3 >= c_lo && px < c_hi && dw >= 1 && dw + 1 < PW) {
                 const unsigned* crow = reinterpret_cast<const unsigned*>(T + row * P) + dw;
                 const unsigned c0 = crow[-1], c1 = crow[0], c2 = crow[1];
@@ -557,32 +568,37 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
                     const fc_us2 dm = __builtin_elementwise_max(__builtin_elementwise_min(n, sq), __builtin_elementwise_min(e, w));
                     kk[h] = fc_u(__builtin_elementwise_sub_sat(bm, (fc_us2)(v + tt))) | fc_u(__builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, tt), dm));
                 }
-                // halves -> 0/1 (v_pk_min_u16), then bits 0..3 = pixels 0..3, masked by the dword's detection columns
-                const unsigned z0 = fc_u(__builtin_elementwise_min(fc_pk(kk[0]), fc_pk(0x00010001u)));
-                const unsigned z1 = fc_u(__builtin_elementwise_min(fc_pk(kk[1]), fc_pk(0x00010001u)));
-                const unsigned zz = z0 | (z1 << 1);
-                keep4 = ((zz & 3u) | ((zz >> 14) & 12u)) & colmask[dw];
+                const uint2 cm = colmask[dw];
+                kk0 = kk[0] & cm.x; kk1 = kk[1] & cm.y;
             }
-            if (__ballot(keep4 != 0u) != 0ull) {               // one LDS atomic per wave and item (a per-lane atomic on the one counter measured slower)
-                const unsigned long long m0 = __ballot((keep4 & 1u) != 0u), m1 = __ballot((keep4 & 2u) != 0u);
-                const unsigned long long m2 = __ballot((keep4 & 4u) != 0u), m3 = __ballot((keep4 & 8u) != 0u);
-                const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-                int base = 0;
-                if (lane == 0) base = atomicAdd(nsurv, n0 + n1 + n2 + n3);
-                base = __builtin_amdgcn_readfirstlane(base);
-                const unsigned long long lt = lanemask_lt();
-                const int pos0 = row * P + px;
-                int q;
-                if ((keep4 & 1u) && (q = base + __popcll(m0 & lt)) < FC_SURV) surv[q] = (unsigned short)pos0;
-                if ((keep4 & 2u) && (q = base + n0 + __popcll(m1 & lt)) < FC_SURV) surv[q] = (unsigned short)(pos0 + 1);
-                if ((keep4 & 4u) && (q = base + n0 + n1 + __popcll(m2 & lt)) < FC_SURV) surv[q] = (unsigned short)(pos0 + 2);
-                if ((keep4 & 8u) && (q = base + n0 + n1 + n2 + __popcll(m3 & lt)) < FC_SURV) surv[q] = (unsigned short)(pos0 + 3);
+            // survivor predicates of the lane's four pixels: one 16-bit compare each on the packed path
+            const bool k0 = PACKED ? (kk0 & 0xFFFFu) != 0u : (keep4 & 1u) != 0u, k1 = PACKED ? (kk1 & 0xFFFFu) != 0u : (keep4 & 2u) != 0u;
+            const bool k2 = PACKED ? (kk0 >> 16) != 0u : (keep4 & 4u) != 0u, k3 = PACKED ? (kk1 >> 16) != 0u : (keep4 & 8u) != 0u;
+            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
+            if ((m0 | m1 | m2 | m3) != 0ull) {
+                // rank of the lane's pixel i among the wave's survivors of this item: pixels 0 of all lanes first, then
+                // pixels 1, ...; v_mbcnt adds the count of lower lanes to the running base
+                const int b1 = wcnt + __popcll(m0), b2 = b1 + __popcll(m1), b3 = b2 + __popcll(m2);
+                const int pos0 = r0 * P + 4 * it;                  // == row * P + px, as P == 4 * PW
+                if (k0) wsurv[fc_mbcnt(m0, wcnt)] = (unsigned short)pos0;
+                if (k1) wsurv[fc_mbcnt(m1, b1)] = (unsigned short)(pos0 + 1);
+                if (k2) wsurv[fc_mbcnt(m2, b2)] = (unsigned short)(pos0 + 2);
+                if (k3) wsurv[fc_mbcnt(m3, b3)] = (unsigned short)(pos0 + 3);
+                wcnt = b3 + __popcll(m3);
             }
         }
+        if (lane == 0) nsurv[4 + wv] = wcnt;
         __syncthreads();
-        const int ns = abl == 2 ? 0 : min(*nsurv, FC_SURV);      // abl 2: no scoring
+        int wfirst[NW + 1];                                    // list index of each wave's first survivor
+        wfirst[0] = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) wfirst[w + 1] = wfirst[w] + nsurv[4 + w];
+        const int ns = abl == 2 ? 0 : wfirst[NW];              // abl 2: no scoring
         for (int si = tid; si < ns; si += FC_TPB) {
-            const int pos = surv[si];
+            int w = 0, j = si;
+#pragma unroll
+            for (int k = 1; k < NW; k++) if (si >= wfirst[k]) { w = k; j = si - wfirst[k]; }
+            const int pos = surv[w * WCAP + j];
             const uint8_t* c = T + pos;
             const int v = c[0];
             int r[16];
@@ -606,9 +622,10 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
     const int rh = bh - 6;
     bool listed = g.min_th <= g.ini_th && nnz <= FC_NZ && B.ncells <= FC_CELLS;
     if (listed) {
+        const unsigned p_inv = 0xFFFFFFFFu / (unsigned)P + 1u;           // pos / P == mulhi(pos, p_inv) for pos < 2^16 and every pitch 16..256 (checked exhaustively)
         for (int e = tid; e < nnz; e += FC_TPB) {
             const int pos = nz[e];
-            const int row = pos / P, col = pos - row * P;
+            const int row = (int)__umulhi((unsigned)pos, p_inv), col = pos - row * P;
             int ci = -1;
             for (int i = 0; i < B.ncells; i++)
                 if (col >= clo[i] && col < clo[i] + cwd[i]) ci = i;

@@ -13,6 +13,7 @@
 #include "ba_types.h"
 #include "ba_math.h"
 #include <rocsolver/rocsolver.h>
+#include <thread>
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
@@ -51,10 +52,15 @@ void sp_launch_add_lambda(hipStream_t, const int* diag, int nfree, double lambda
 void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs);
 size_t pcg_minv_bytes(int nfree);
 hipError_t pcg_launch_minv(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int nfree, double* Minv, int* bad);
-void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc);
+void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C);
 void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc, int parity);
-void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc);
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int parity, const PcgCoarse& C);
+void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc, const PcgCoarse& C);
+int pcg_coarse_dim(int nfree);
+int pcg_coarse_parts(int nfree);
+void pcg_launch_coarse_build(hipStream_t, const double* Hb, const uint8_t* map, const int* id, int nfree, double* Ac);
+void pcg_launch_coarse_mirror(hipStream_t, double* A, int nc);
+void pcg_launch_coarse_identity(hipStream_t, double* A, int nc);
 void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_update(hipStream_t, const BaDev&);
 int ba_scale_blocks(const BaDev&);
@@ -65,17 +71,23 @@ void ba_launch_deactivate(hipStream_t, const BaDev&, const uint8_t* flag);
 
 struct BaState {
     rocblas_handle blas = nullptr;
+    rocblas_handle blas_side = nullptr;    // coarse-level inversion, on `side`, concurrent with the PCG of the current trial
+    hipStream_t side = nullptr;
+    int side_warm_nc = 0;              // coarse size rocSOLVER has been warmed up for
     double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
     DevBuf poses, Rt, intr, free_of, pose_of_free, points, edge_pose, edge_point, obs, info, active, err,
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
            partial, scal, flags, info_dev, tmp_ll, pp_diag, gather,
            sp_cnt, sp_off, sp_key, sp_val, sp_key2, sp_val2, sp_map, sp_id, sp_tmp, blk_row, blk_col, diag_id, seg_start, seg_end,
-           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc;
+           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw;
 };
 void ba_state_free(BaState* s)
 {
     if (!s) return;
+    if (s->side) (void)hipStreamSynchronize(s->side);
     if (s->blas) (void)rocblas_destroy_handle(s->blas);
+    if (s->blas_side) (void)rocblas_destroy_handle(s->blas_side);
+    if (s->side) (void)hipStreamDestroy(s->side);
     if (s->pinned) (void)hipHostFree(s->pinned);
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
                       &s->obs, &s->info, &s->active, &s->err, &s->pt_first, &s->pose_first, &s->pose_edges, &s->Hpp, &s->bp,
@@ -83,7 +95,7 @@ void ba_state_free(BaState* s)
                       &s->partial, &s->scal, &s->flags, &s->info_dev, &s->tmp_ll, &s->pp_diag, &s->gather,
                       &s->sp_cnt, &s->sp_off, &s->sp_key, &s->sp_val, &s->sp_key2, &s->sp_val2, &s->sp_map, &s->sp_id, &s->sp_tmp, &s->blk_row,
                       &s->blk_col, &s->diag_id, &s->seg_start, &s->seg_end, &s->ent_key, &s->ent_val, &s->ent_key2, &s->ent_val2, &s->row_ptr,
-                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc };
+                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc, &s->pcg_aci, &s->pcg_coarse, &s->pcg_acw };
     for (DevBuf* b : all) b->release();
     delete s;
 }
@@ -165,12 +177,14 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     if (!S.blas) {
         if (rocblas_create_handle(&S.blas) != rocblas_status_success) { S.blas = nullptr; return ccm_fail(c, CCM_E_DEVICE, "rocblas_create_handle failed"); }
         rocblas_set_stream(S.blas, c->stream);
+        rocblas_set_atomics_mode(S.blas, rocblas_atomics_not_allowed);   // the ranks of a sharded solve must compute the same bits
     }
     if (!S.pinned && hipHostMalloc((void**)&S.pinned, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         S.pinned = nullptr;
         return ccm_fail(c, CCM_E_NOMEM, "hipHostMalloc failed");
     }
     hipStream_t st = c->stream;
+    if (S.side) CCM_HIP(c, hipStreamSynchronize(S.side));      // an earlier call that ended on an error may have left work there
     const int ranks = comm_ranks(c), rank = comm_rank(c);
     ccm_ba_result local{};
     if (!res) res = &local;
@@ -319,6 +333,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         CCM_RESERVE(c, S.Minv, pcg_minv_bytes(nfree)); CCM_RESERVE(c, S.pcg_w, 6 * (size_t)n * 8 + 64);
         CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)n / 192 + 4) * 3 * 8 + 64);
         CCM_RESERVE(c, S.pcg_sc, 64 * 8);
+        {
+            const size_t nc = (size_t)pcg_coarse_dim(nfree);
+            CCM_RESERVE(c, S.pcg_aci, nc * nc * 8 + 64); CCM_RESERVE(c, S.pcg_acw, nc * nc * 8 + 64);
+            CCM_RESERVE(c, S.pcg_coarse, ((size_t)n + nc + (size_t)pcg_coarse_parts(nfree) + 64) * 8);    // rcl (<= n), yc, cpart
+        }
         CCM_HIP(c, hipGetLastError());
     }
     CCM_RESERVE(c, S.Y, std::max<size_t>(18 * (size_t)E * 8, 16)); CCM_RESERVE(c, S.db, std::max<size_t>(3 * (size_t)L * 8, 16));
@@ -328,28 +347,66 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // dense Cholesky for small systems (exact, and cheaper than PCG start-up), PCG on the packed blocks otherwise
     static const int dense_max = getenv("CCM_BA_DENSE_MAX") ? atoi(getenv("CCM_BA_DENSE_MAX")) : 1536;
     const bool use_pcg = n > dense_max;
+    // second preconditioner level (ba_sparse.hip): on for systems with at least 64 coarse unknowns
+    static const bool want_coarse = !(getenv("CCM_PCG_COARSE") && atoi(getenv("CCM_PCG_COARSE")) == 0);
+    PcgCoarse PC{};
+    const int nc = nfree > 0 ? pcg_coarse_dim(nfree) : 0;
+    if (use_pcg && want_coarse && nc >= 64) {
+        if (!S.side) {
+            if (hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess) { S.side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed"); }
+            if (rocblas_create_handle(&S.blas_side) != rocblas_status_success) { S.blas_side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "rocblas_create_handle failed"); }
+            rocblas_set_stream(S.blas_side, S.side);
+            rocblas_set_atomics_mode(S.blas_side, rocblas_atomics_not_allowed);
+            S.side_warm_nc = 0;
+        }
+        if (S.side_warm_nc != nc) {
+            // the first potrf / potri of a size loads rocSOLVER's kernels and sizes its workspace (a quarter of a second):
+            // do that here, on the identity, instead of inside the first trial that starts an inversion
+            CCM_HIP(c, hipMemsetAsync(S.pcg_acw.p, 0, (size_t)nc * nc * 8, S.side));
+            pcg_launch_coarse_identity(S.side, S.pcg_acw.as<double>(), nc);
+            if (rocsolver_dpotrf(S.blas_side, rocblas_fill_lower, nc, S.pcg_acw.as<double>(), nc, S.info_dev.as<int>() + 4) != rocblas_status_success ||
+                rocsolver_dpotri(S.blas_side, rocblas_fill_lower, nc, S.pcg_acw.as<double>(), nc, S.info_dev.as<int>() + 5) != rocblas_status_success)
+                return ccm_fail(c, CCM_E_DEVICE, "rocsolver potrf/potri warm-up failed");
+            CCM_HIP(c, hipStreamSynchronize(S.side));
+            S.side_warm_nc = nc;
+        }
+        PC.Aci = S.pcg_aci.as<double>();
+        PC.rcl = S.pcg_coarse.as<double>();
+        PC.yc = PC.rcl + n;
+        PC.cpart = PC.yc + nc;
+    }
     // The PCG inner loop is two small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
     const int pcg_chunk = 16;                     // even: the r.z slot parity is the same at the start of every chunk
-    hipGraph_t pcg_graph = nullptr; hipGraphExec_t pcg_exec = nullptr;
-    struct GraphGuard { hipGraph_t& g; hipGraphExec_t& e; ~GraphGuard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } graph_guard{pcg_graph, pcg_exec};
+    // Two graphs: the cluster level alone (first trial of a call: no coarse inverse exists yet) and both levels.
+    PcgCoarse PC0{};
+    hipGraph_t pcg_graph[2] = {nullptr, nullptr}; hipGraphExec_t pcg_exec[2] = {nullptr, nullptr};
+    struct GraphGuard { hipGraph_t* g; hipGraphExec_t* e; ~GraphGuard() { for (int i = 0; i < 2; i++) { if (e[i]) (void)hipGraphExecDestroy(e[i]); if (g[i]) (void)hipGraphDestroy(g[i]); } } } graph_guard{pcg_graph, pcg_exec};
     if (use_pcg && nfree > 0) {
         CCM_HIP(c, hipStreamSynchronize(st));
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
-            for (int k = 0; k < pcg_chunk; k++)
-                pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1);
-            pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
-            hipError_t e1 = hipStreamEndCapture(st, &pcg_graph);
-            hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec, pcg_graph, nullptr, nullptr, 0) : e1;
-            if (e2 != hipSuccess) {
-                pcg_exec = nullptr;                     // fall back to plain launches
-                if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph capture failed: %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
-                (void)hipGetLastError();
-            }
-        } else { if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] hipStreamBeginCapture failed\n"); (void)hipGetLastError(); }
-        if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph %s\n", pcg_exec ? "ready" : "not used");
+        for (int lv = 0; lv < (PC.Aci ? 2 : 1); lv++) {
+            const PcgCoarse& pc = lv ? PC : PC0;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                for (int k = 0; k < pcg_chunk; k++)
+                    pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                                    nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pc);
+                pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pc);
+                hipError_t e1 = hipStreamEndCapture(st, &pcg_graph[lv]);
+                hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec[lv], pcg_graph[lv], nullptr, nullptr, 0) : e1;
+                if (e2 != hipSuccess) {
+                    pcg_exec[lv] = nullptr;                     // fall back to plain launches
+                    if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph capture failed: %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
+                    (void)hipGetLastError();
+                }
+            } else { if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] hipStreamBeginCapture failed\n"); (void)hipGetLastError(); }
+            if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph %d %s\n", lv, pcg_exec[lv] ? "ready" : "not used");
+        }
     }
+    static const bool side_thread = !(getenv("CCM_PCG_SIDE_THREAD") && atoi(getenv("CCM_PCG_SIDE_THREAD")) == 0);
+    bool coarse_ready = false, coarse_pending = false;     // an inverse is in Aci / an inversion is running on the side stream
+    // rocSOLVER spends about two milliseconds of HOST time enqueuing the kernels of one potrf + potri; a helper thread does
+    // that while this thread keeps the PCG of the current trial going.  Joined before the next trial looks at the result.
+    struct SideJob { std::thread th; int status = 0; void join() { if (th.joinable()) th.join(); } ~SideJob() { join(); } } side_job;
 
     auto stop_requested = [&]() { return opt->stop_flag && *opt->stop_flag; };
     // chi2 (+ optionally scale) of the current state, summed over ranks
@@ -425,7 +482,42 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         int* bad = info_dev + 1;
                         CCM_HIP(c, hipMemsetAsync(bad, 0, 4, st));
                         CCM_HIP(c, pcg_launch_minv(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, nfree, S.Minv.as<double>(), bad));
-                        pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>());
+                        // Coarse level, pipelined: the inverse this trial uses was computed from the PREVIOUS trial's system on
+                        // the side stream while that trial's PCG ran (a preconditioner may be stale: lambda differs by the LM
+                        // factor, H by one relinearisation); this trial's system starts the next inversion.  Which inverse a
+                        // trial uses depends only on the trial number, never on timing, so all ranks do the same.
+                        if (PC.Aci && coarse_pending) {
+                            side_job.join();
+                            if (side_job.status) return ccm_fail(c, CCM_E_DEVICE, "potrf/potri of the coarse matrix failed on the side stream");
+                            CCM_HIP(c, hipStreamSynchronize(S.side));                    // the inversion has normally been over for milliseconds
+                            CCM_HIP(c, hipMemcpyAsync(PC.Aci, S.pcg_acw.p, (size_t)nc * nc * 8, hipMemcpyDeviceToDevice, st));
+                            int cinfo[2] = {0, 0};
+                            CCM_HIP(c, hipMemcpyAsync(cinfo, info_dev + 4, 8, hipMemcpyDeviceToHost, st));
+                            CCM_HIP(c, hipStreamSynchronize(st));
+                            coarse_pending = false; coarse_ready = cinfo[0] == 0 && cinfo[1] == 0;     // a system that was not positive definite leaves no usable inverse
+                        }
+                        const bool more_trials_planned = it + 1 < iterations || (stage == 0 && opt->iterations2 > 0);
+                        if (PC.Aci && more_trials_planned) {
+                            double* Aw = S.pcg_acw.as<double>();
+                            pcg_launch_coarse_build(st, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, Aw);   // row-major upper == column-major lower
+                            CCM_HIP(c, hipStreamSynchronize(st));                        // the side stream may start as soon as its kernels are enqueued
+                            BaState* sp = &S;
+                            const int dev = c->device, ncc = nc;
+                            int* inf = info_dev;
+                            int* status = &side_job.status;
+                            side_job.th = std::thread([sp, dev, ncc, Aw, inf, status]() {
+                                int bad_calls = hipSetDevice(dev) != hipSuccess;
+                                bad_calls |= rocsolver_dpotrf(sp->blas_side, rocblas_fill_lower, ncc, Aw, ncc, inf + 4) != rocblas_status_success;
+                                bad_calls |= rocsolver_dpotri(sp->blas_side, rocblas_fill_lower, ncc, Aw, ncc, inf + 5) != rocblas_status_success;
+                                pcg_launch_coarse_mirror(sp->side, Aw, ncc);
+                                *status = bad_calls;
+                            });
+                            if (!side_thread) side_job.join();
+                            coarse_pending = true;
+                        }
+                        const PcgCoarse& pcu = coarse_ready ? PC : PC0;
+                        hipGraphExec_t gexec = pcg_exec[coarse_ready ? 1 : 0];
+                        pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                         const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
                         static const double env_tol = getenv("CCM_PCG_TOL") ? atof(getenv("CCM_PCG_TOL")) : 0.0;
                         const double pcg_tol = env_tol > 0 ? env_tol : (opt->pcg_tol > 0 ? opt->pcg_tol : 1e-8);   // relative residual
@@ -439,14 +531,14 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                             if (badh || !(sc[3] > 0.0) || !std::isfinite(sc[2])) { ok2 = 0; solved = true; break; }   // not positive definite
                             if (sc[2] <= tol2 * sc[1]) { solved = true; break; }
                             if (itc >= max_it) break;
-                            const int reps = itc < 64 ? 2 : 1;             // few host round trips while far from convergence
+                            const int reps = (itc < 64 && !coarse_ready) ? 2 : 1;       // few host round trips while far from convergence
                             for (int rpt = 0; rpt < reps; rpt++) {
-                                if (pcg_exec) CCM_HIP(c, hipGraphLaunch(pcg_exec, st));
+                                if (gexec) CCM_HIP(c, hipGraphLaunch(gexec, st));
                                 else {
                                     for (int k = 0; k < pcg_chunk; k++)
                                         pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1);
-                                    pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>());
+                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pcu);
+                                    pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                                 }
                             }
                             itc += reps * pcg_chunk;
@@ -479,6 +571,21 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     CCM_HIP(c, hipStreamSynchronize(st));
                     t2 = clk::now();
                     res->t_schur += secs(t1, t2);
+                }
+                if (ranks > 1 && nfree > 0) {
+                    // Every rank has solved the same reduced system, but rocSOLVER's factorisations (dense path, coarse
+                    // preconditioner) are only reproducible to rounding.  Rank 0's increment -- and its verdict on positive
+                    // definiteness -- is the one all ranks apply, so their poses stay bit-identical: the others contribute zeros
+                    // to a sum all-reduce (x + 0 is exact).
+                    double* flag = scal + 3;
+                    S.pinned[12] = (rank == 0 && ok2) ? 1.0 : 0.0;
+                    CCM_HIP(c, hipMemcpyAsync(flag, S.pinned + 12, 8, hipMemcpyHostToDevice, st));
+                    if (rank != 0 || !ok2) CCM_HIP(c, hipMemsetAsync(D.x, 0, (size_t)n * 8, st));
+                    if ((rc = comm_allreduce_f64(c, D.x, (size_t)n, false))) return rc;
+                    if ((rc = comm_allreduce_f64(c, flag, 1, false))) return rc;
+                    CCM_HIP(c, hipMemcpyAsync(S.pinned + 12, flag, 8, hipMemcpyDeviceToHost, st));
+                    CCM_HIP(c, hipStreamSynchronize(st));
+                    ok2 = S.pinned[12] != 0.0;
                 }
                 auto t3 = clk::now();
                 res->t_solve += secs(t2, t3);
@@ -513,6 +620,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         }
     }
 
+    side_job.join();
+    if (S.side) CCM_HIP(c, hipStreamSynchronize(S.side));
     // ---- results
     CCM_HIP(c, hipMemcpyAsync(pb->poses, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToHost, st));
     if (ranks == 1) {

@@ -292,12 +292,124 @@ __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, 
     if (!ok && threadIdx.x == 0) atomicOr(bad, 1);
 }
 
+// Second level of the preconditioner (additive two-level Schwarz): the cluster inverses above damp the error inside a
+// cluster, but the slowly varying error along the trajectory (many keyframes drifting together) converges only as fast as
+// information travels from cluster to cluster.  The coarse space has 6 unknowns per aggregate of PCG_AGG clusters
+// (one rigid increment shared by the aggregate's keyframes: R sums the 6-vectors of an aggregate), its matrix
+// Ac = R H R^T is dense and small (6 nagg squared), inverted once per LM trial (rocSOLVER potrf + potri), and
+//   z = Minv r + R^T Ac^-1 R r.
+// Measured on the 2000-keyframe graph (first LM trial, relative residual 1e-8): 345 PCG iterations with the cluster
+// level alone, 137 with 16-keyframe aggregates, 112 with 8-keyframe aggregates.
+#ifndef PCG_AGG
+#define PCG_AGG 2
+#endif
+#define PCG_AG_KF (PCG_CL * PCG_AGG)
+static_assert(PCG_AG_KF <= 64, "a wave spreads a coarse value over its aggregate's keyframes, one per lane");
+// upper triangle of Ac, row-major (== column-major lower for rocSOLVER): one workgroup per aggregate pair I <= J, thread =
+// keyframe pair (i, j), the 36 sums reduced over the workgroup in a fixed order (the ranks of a sharded solve must get
+// the same bits)
+__global__ __launch_bounds__(256) void k_pcg_coarse_build(const double* __restrict__ Hb, const uint8_t* __restrict__ map, const int* __restrict__ id,
+                                                          int nfree, int nagg, double* __restrict__ Ac)
+{
+    __shared__ double red[4][36];
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (J < I) return;
+    const int i0 = I * PCG_AG_KF, j0 = J * PCG_AG_KF;
+    const int ni = min(PCG_AG_KF, nfree - i0), nj = min(PCG_AG_KF, nfree - j0);
+    double acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; e++) acc[e] = 0.0;
+    for (int t = threadIdx.x; t < ni * nj; t += 256) {
+        const int i = i0 + t / nj, j = j0 + t % nj;
+        const int a = min(i, j), b = max(i, j);
+        const long long idx = (long long)a * nfree + b;
+        if (!map[idx]) continue;
+        const double* B = Hb + 36LL * id[idx];
+#pragma unroll
+        for (int d = 0; d < 6; d++)
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+                // block (a, b) is stored for a <= b; (i, j) with i > j is its transpose; of a diagonal block the upper half counts
+                const double v = i < j ? B[6 * d + e] : (i > j ? B[6 * e + d] : (d <= e ? B[6 * d + e] : B[6 * e + d]));
+                acc[6 * d + e] += v;
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 36; e++) {
+        double v = acc[e];
+        for (int st = 32; st >= 1; st >>= 1) v += __shfl_xor(v, st, 64);
+        acc[e] = v;
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < 36; e++) red[threadIdx.x >> 6][e] = acc[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int d = threadIdx.x / 6, e = threadIdx.x - 6 * d;
+        const int r = 6 * I + d, c = 6 * J + e;
+        if (r <= c) Ac[(long long)r * (6 * nagg) + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+// the inverse comes back in the same triangle: fill the other one
+__global__ __launch_bounds__(256) void k_pcg_coarse_mirror(double* __restrict__ A, int nc)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= (long long)nc * nc) return;
+    const int r = (int)(i / nc), c = (int)(i - (long long)r * nc);
+    if (r > c) A[i] = A[(long long)c * nc + r];
+}
+// yc = Ac^-1 (R r), z += R^T yc: rcl holds the per-cluster sums of the residual (written by k_pcg_init / k_pcg_update), a
+// wave per coarse row (aggregate I, component d) which then adds its value to component d of the aggregate's keyframes;
+// cpart[workgroup] = the workgroup's share of (R r) . yc, which is the coarse level's contribution to r.z
+__global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ Aci, int nc, const double* __restrict__ rcl, int ncl,
+                                                    double* __restrict__ yc, double* __restrict__ cpart, double* __restrict__ z, int nfree)
+{
+    extern __shared__ double rc[];
+    __shared__ double dots[4];
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const int I = i / 6, d = i - 6 * I;
+        double s = 0;
+#pragma unroll
+        for (int a = 0; a < PCG_AGG; a++) { const int cl = I * PCG_AGG + a; if (cl < ncl) s += rcl[6 * cl + d]; }
+        rc[i] = s;
+    }
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wv;
+    double s = 0;
+    if (row < nc) {
+        const double* A = Aci + (long long)row * nc;
+        for (int c = lane; c < nc; c += 64) s += A[c] * rc[c];
+    }
+    for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
+    if (row < nc && lane < PCG_AG_KF) {
+        const int I = row / 6, kf = I * PCG_AG_KF + lane;
+        if (kf < nfree) z[6LL * kf + (row - 6 * I)] += s;
+    }
+    if (lane == 0) { if (row < nc) yc[row] = s; dots[wv] = row < nc ? s * rc[row] : 0.0; }
+    __syncthreads();
+    if (threadIdx.x == 0) cpart[blockIdx.x] = ((dots[0] + dots[1]) + dots[2]) + dots[3];
+}
+
 // state vector layout in `w`: x | r | z | p (even iterations) | Ap | p (odd iterations)  (each n doubles); scalars in sc[]:
 //   sc[0] rz, sc[1] |b|^2, sc[2] |r|^2, sc[3] min p.Ap seen, sc[4] iterations
 #define PCG_UPD_TPB 192       // 4 clusters of PCG_CN scalars: a cluster never straddles two blocks
 static_assert(PCG_UPD_TPB % PCG_CN == 0, "a block must hold whole clusters");
+// R r, first half: the 6 component sums of every cluster of the block (threads 0..5 of a cluster, keyframes in order)
+__device__ __forceinline__ void pcg_cluster_sums(const double* rs, double* __restrict__ rcl, int nfree)
+{
+    if (!rcl) return;
+    const int li = threadIdx.x % PCG_CN, cl = (int)(((long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x) / PCG_CN);
+    if (li < 6 && cl < (nfree + PCG_CL - 1) / PCG_CL) {
+        const double* q = rs + (threadIdx.x - li) + li;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < PCG_CL; k++) s += q[6 * k];
+        rcl[6 * cl + li] = s;
+    }
+}
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restrict__ b, const double* __restrict__ Minv, int nfree,
-                                                          double* __restrict__ w, double* __restrict__ part)
+                                                          double* __restrict__ w, double* __restrict__ part, double* __restrict__ rcl)
 {
     __shared__ double rs[PCG_UPD_TPB];
     __shared__ double red[2][3];
@@ -306,6 +418,7 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restri
     const double ri = o < n ? b[o] : 0.0;
     rs[threadIdx.x] = ri;
     __syncthreads();
+    pcg_cluster_sums(rs, rcl, nfree);
     double rz = 0, bb = 0;
     if (o < n) {
         const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
@@ -325,11 +438,14 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restri
         part[3 * blockIdx.x + 2] = 1e300;
     }
 }
-__global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ part, int nblk, double* __restrict__ sc)
+__global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ part, int nblk, const double* __restrict__ cpart, int ncpart,
+                                                     double* __restrict__ sc)
 {
     if (threadIdx.x != 0) return;
-    double rz = 0, bb = 0;
+    double rz = 0, bb = 0, rzc = 0;
     for (int i = 0; i < nblk; i++) { rz += part[3 * i]; bb += part[3 * i + 1]; }
+    for (int i = 0; i < ncpart; i++) rzc += cpart[i];
+    rz += rzc;
     sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0; sc[8] = rz; sc[9] = rz;
 }
 
@@ -341,7 +457,8 @@ __global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ 
 // Thread = (entry slot 0..41, row component 0..5); the 42 slot sums of a component are added in slot order by one lane.
 __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb, const int* __restrict__ row_ptr, const unsigned* __restrict__ ent_key,
                                                   const unsigned* __restrict__ ent_val, int nfree, double* __restrict__ w, double* __restrict__ pap_part,
-                                                  int nblk_part, const double* __restrict__ part, double* __restrict__ sc, int parity)
+                                                  int nblk_part, const double* __restrict__ part, double* __restrict__ sc, int parity,
+                                                  const double* __restrict__ cpart, int ncpart)
 {
     __shared__ double red[42][6];
     __shared__ double s_beta;
@@ -350,7 +467,10 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
     if (threadIdx.x < 64) {
         double rz = 0, rr = 0;
         for (int i = threadIdx.x; i < nblk_part; i += 64) { rz += part[3 * i]; rr += part[3 * i + 1]; }
-        for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); }
+        double rzc = 0;
+        for (int i = threadIdx.x; i < ncpart; i += 64) rzc += cpart[i];
+        for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); rzc += __shfl_xor(rzc, st, 64); }
+        rz += rzc;
         if (threadIdx.x == 0) {
             const double rz_prev = sc[8 + parity];
             s_beta = rz_prev > 0.0 ? rz / rz_prev : 0.0;
@@ -422,7 +542,7 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
 // block holds 4 whole clusters whose new residuals are shared through LDS.  Every block re-reduces p.Ap itself.
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __restrict__ Minv, int nfree, double* __restrict__ w,
                                                             const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part,
-                                                            int parity)
+                                                            int parity, double* __restrict__ rcl)
 {
     __shared__ double red[4];
     __shared__ double red2[2][3];
@@ -444,6 +564,7 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     const double ri = r_old - alpha * ap;
     rs[threadIdx.x] = ri;
     __syncthreads();
+    pcg_cluster_sums(rs, rcl, nfree);
     double rz = 0, rr = 0;
     if (o < n) {
         const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
@@ -464,11 +585,14 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     }
 }
 
-__global__ __launch_bounds__(64) void k_pcg_scalars(int nblk, const double* __restrict__ part, double* __restrict__ sc)
+__global__ __launch_bounds__(64) void k_pcg_scalars(int nblk, const double* __restrict__ part, const double* __restrict__ cpart, int ncpart,
+                                                    double* __restrict__ sc)
 {
     if (threadIdx.x != 0) return;
-    double rz = 0, rr = 0;
+    double rz = 0, rr = 0, rzc = 0;
     for (int i = 0; i < nblk; i++) { rz += part[3 * i]; rr += part[3 * i + 1]; }
+    for (int i = 0; i < ncpart; i++) rzc += cpart[i];
+    rz += rzc;
     const double pap = part[2];
     sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;
 }
@@ -547,22 +671,51 @@ hipError_t pcg_launch_minv(hipStream_t s, const double* Hb, const int* blk_row, 
     hipLaunchKernelGGL(k_pcg_cl_invert, dim3(ncl), dim3(256), 0, s, Minv, nfree, bad);
     return hipSuccess;
 }
-void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc)
+// coarse level: sizes, set-up (Ac into `Ac`, upper triangle row-major; the caller factors and inverts it, then mirrors)
+int pcg_coarse_dim(int nfree) { return 6 * nblk(nfree, PCG_AG_KF); }
+int pcg_coarse_parts(int nfree) { return nblk(pcg_coarse_dim(nfree), 4); }
+void pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, double* Ac)
 {
-    const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
-    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part);
-    hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, sc);
+    const int nagg = nblk(nfree, PCG_AG_KF);
+    hipLaunchKernelGGL(k_pcg_coarse_build, dim3(nagg, nagg), dim3(256), 0, s, Hb, map, id, nfree, nagg, Ac);
 }
-// one PCG iteration = two kernels (direction + mat-vec, then the vector updates with the preconditioner)
-void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
-                     int nfree, double* w, double* pap_part, double* part, double* sc, int parity)
+void pcg_launch_coarse_mirror(hipStream_t s, double* A, int nc)
+{
+    hipLaunchKernelGGL(k_pcg_coarse_mirror, dim3(nblk((long long)nc * nc, 256)), dim3(256), 0, s, A, nc);
+}
+__global__ __launch_bounds__(256) void k_pcg_coarse_identity(double* __restrict__ A, int nc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nc) A[(long long)i * nc + i] = 1.0;
+}
+void pcg_launch_coarse_identity(hipStream_t s, double* A, int nc) { hipLaunchKernelGGL(k_pcg_coarse_identity, dim3(nblk(nc, 256)), dim3(256), 0, s, A, nc); }
+static void pcg_launch_coarse(hipStream_t s, const PcgCoarse& C, int nfree, double* w)
+{
+    const int nc = pcg_coarse_dim(nfree);
+    hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, C.rcl, nblk(nfree, PCG_CL), C.yc, C.cpart,
+                       w + 2 * 6LL * nfree, nfree);
+}
+void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C)
 {
     const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
-    hipLaunchKernelGGL(k_pcg_spmv, dim3(nfree), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity);
-    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity);
+    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part, C.Aci ? C.rcl : nullptr);
+    if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
+    hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
+}
+// one PCG iteration = direction + mat-vec, then the vector updates with the cluster level, then the coarse level
+void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
+                     int nfree, double* w, double* pap_part, double* part, double* sc, int parity, const PcgCoarse& C)
+{
+    const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
+    const int ncp = C.Aci ? pcg_coarse_parts(nfree) : 0;
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(nfree), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity,
+                       C.cpart, ncp);
+    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity, C.Aci ? C.rcl : nullptr);
+    if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
 }
 // publish the scalars of the last iteration (before the host reads them)
-void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc)
+void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc, const PcgCoarse& C)
 {
-    hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nblk(6LL * nfree, PCG_UPD_TPB), part, sc);
+    hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nblk(6LL * nfree, PCG_UPD_TPB), part, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
 }
+

@@ -27,3 +27,11 @@ struct BaDev {
     double* Hs; double* bs;        // (6 nfree)^2 row-major, upper block triangle; 6 nfree
     double* x;                     // [6 nfree + 3 L]
 };
+
+// coarse level of the PCG preconditioner (ba_sparse.hip); Aci == nullptr switches it off
+struct PcgCoarse {
+    double* Aci;                   // [nc][nc] inverse of the coarse matrix, nc = 6 per aggregate
+    double* rcl;                   // [clusters][6] per-cluster sums of the residual
+    double* yc;                    // [nc] coarse correction
+    double* cpart;                 // per workgroup of k_pcg_coarse: share of (R r) . yc
+};

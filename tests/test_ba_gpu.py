@@ -86,15 +86,35 @@ def test_full_gba_properties(ctx):
     assert r3["chi2_final"] < 0.2 * r3["chi2_initial"] and r6["chi2_final"] <= r3["chi2_final"] * (1 + 1e-12)
     assert (r6["poses"][0] == g["poses"][0]).all()
     again = Optimizer.MapFusionGBA(g, 3, ctx=ctx)
-    assert (again["poses"] == r3["poses"]).all() and (again["points"] == r3["points"]).all()      # fixed summation orders: bit-reproducible
+    # every kernel of this library sums in a fixed order; the coarse level of the preconditioner is inverted by rocSOLVER,
+    # whose potrf was seen to differ in the last bits from run to run, so repeatability is to rounding (measured 5e-13),
+    # and bit for bit with the cluster level alone (checked in a child process below)
+    assert np.abs(again["poses"] - r3["poses"]).max() < 1e-9 and np.abs(again["points"] - r3["points"]).max() < 1e-9
     e0 = pose_delta(g["poses"], g["gt_poses"]); e1 = pose_delta(r6["poses"], g["gt_poses"])
     assert np.median(e1) < 0.25 * np.median(e0)
+    import subprocess, sys
+    code = r"""
+import numpy as np
+from motioncheck_ccm_slam_amd import _lib, synth
+from motioncheck_ccm_slam_amd.optimizer import Optimizer
+ctx = _lib.Context(0); g = synth.gba_graph()
+a = Optimizer.MapFusionGBA(g, 3, ctx=ctx); b = Optimizer.MapFusionGBA(g, 3, ctx=ctx)
+assert (a["poses"] == b["poses"]).all() and (a["points"] == b["points"]).all()
+assert a["pcg_iterations"] > 0
+print("ok")
+"""
+    env = dict(os.environ, CCM_PCG_COARSE="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_iterative_solver_forced_on_small_graphs():
+@pytest.mark.parametrize("coarse", ["1", "0"])
+def test_iterative_solver_forced_on_small_graphs(coarse):
     """The reduced-camera PCG (cluster-Jacobi, HIP graph) normally starts above 256 free keyframes, where the oracle's
     dense solve is too slow to compare with.  A child process with CCM_BA_DENSE_MAX=0 runs the oracle-sized graphs
-    through it: odd cluster sizes (13, 60 and 239 free keyframes), robust and two-stage schedules."""
+    through it: odd cluster sizes (13, 60 and 239 free keyframes), robust and two-stage schedules.  coarse = 1: the
+    239-keyframe graph also runs the second preconditioner level (coarse inverse pipelined on the side stream); 0: the
+    cluster level alone."""
     import subprocess, sys
     code = r'''
 import numpy as np
@@ -117,7 +137,7 @@ for kf, pts, its in ((60, 3000, 8), (240, 20000, 4)):
     assert pose_delta(strict["poses"], ref["poses"]).max() <= 1e-9
 print("ok")
 '''
-    env = dict(os.environ, CCM_BA_DENSE_MAX="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, CCM_BA_DENSE_MAX="0", CCM_PCG_COARSE=coarse, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
 
@@ -126,8 +146,9 @@ print("ok")
 def test_sharded_gba_two_ranks_on_one_gpu(dense_max, tmp_path):
     """Multi-GPU global BA rehearsed on one GPU: two processes = two ranks, each keeps the landmarks of its range,
     the partial reduced camera systems are summed through the shared-memory transport (RCCL's place).  Both ranks must
-    return the same poses and points, and they must agree with the CPU oracle.  dense_max 0 = PCG (replicated solve,
-    bit-identical on the ranks), large = rocSOLVER Cholesky (the library does not promise bit-reproducibility: 1e-12)."""
+    return the same poses and points, and they must agree with the CPU oracle.  dense_max 0 = PCG, large = rocSOLVER
+    Cholesky; the solve is replicated and rank 0's increment is the one every rank applies (one small all-reduce per
+    trial), so the ranks are bit-identical with either solver."""
     import subprocess, sys, uuid
     code = r'''
 import sys
@@ -166,10 +187,7 @@ print("ok")
     for rc, o, e in outs:
         assert rc == 0 and o.strip().endswith("ok"), o[-1500:] + e[-1500:]
     a, b = np.load(files[0]), np.load(files[1])
-    if dense_max == "0":
-        assert (a["poses"] == b["poses"]).all() and (a["points"] == b["points"]).all(), "the ranks disagree on the result"
-    else:
-        assert np.abs(a["poses"] - b["poses"]).max() < 1e-12 and np.abs(a["points"] - b["points"]).max() < 1e-12
+    assert (a["poses"] == b["poses"]).all() and (a["points"] == b["points"]).all(), "the ranks disagree on the result"
     assert int(a["pairs"]) > 0 and int(b["pairs"]) > 0 and int(a["pairs"]) != int(b["pairs"])      # each rank enumerated its own share
 
 
@@ -195,6 +213,7 @@ ctx.close(); ctx0.close()
 print("ok")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PYTHONPATH=root, CCM_BA_DENSE_MAX="0", CCM_COMM_RCCL_SINGLE="1")
+    # the cluster level alone: the comparison is bit for bit, which rocSOLVER's inversion of the coarse level does not promise
+    env = dict(os.environ, PYTHONPATH=root, CCM_BA_DENSE_MAX="0", CCM_COMM_RCCL_SINGLE="1", CCM_PCG_COARSE="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]

@@ -126,6 +126,9 @@ typedef int hm_v16i __attribute__((ext_vector_type(16)));
 #ifndef HM_WAVES
 #define HM_WAVES 4
 #endif
+#ifndef HM_TT
+#define HM_TT 1                  // 32-train tiles staged per barrier; measured at 10 k pairs: 1 -> 2.34 ms, 2 -> 2.32, 4 (2 WG/CU) -> 2.77
+#endif
 #ifndef HM_WG_PER_CU
 #define HM_WG_PER_CU 4           // measured at 10 k pairs: 4 -> 2.32 ms, 3 -> 2.48 ms
 #endif
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(HM_TPB, HM_WG_PER_CU * HM_TPB / 256) void k_hamming
     int nq, int nt, const int* __restrict__ nq_n, const int* __restrict__ nt_n, int q_blocks,
     int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_dist)
 {
-    __shared__ hm_v4i frag[2][8][64];          // [buffer][k-step][lane]: 16 expanded bytes
+    __shared__ hm_v4i frag[2][HM_TT * 8][64];  // [buffer][sub-tile, k-step][lane]: 16 expanded bytes
     __shared__ __attribute__((aligned(16))) int wall[HM_MAX_NT];   // per train: (popc + HM_BIAS) << 11 | index, HM_SENT past the live count
     const int pair = blockIdx.x / q_blocks, qblk = blockIdx.x - pair * q_blocks;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, r = lane & 31;
@@ -203,23 +206,24 @@ __global__ __launch_bounds__(HM_TPB, HM_WG_PER_CU * HM_TPB / 256) void k_hamming
     //      tile ahead (issued before the MFMAs of the current tile) so that no wave waits on a global load.
     // fragment f of a tile (512 of them): lane half f >> 8, k-step (f >> 5) & 7, train f & 31; thread t owns
     // fragments t, t + HM_TPB, ... (with 256 threads: both halves of one dword)
-    constexpr int HM_FPT = (512 + HM_TPB - 1) / HM_TPB;
+    // HM_TT tiles are staged per barrier ("group")
+    constexpr int HM_FPT = (512 * HM_TT + HM_TPB - 1) / HM_TPB;
     struct Raw { unsigned v[HM_FPT]; };
-    auto fetch = [&](int tile) {
+    auto fetch = [&](int group) {
         Raw x;
 #pragma unroll
         for (int j = 0; j < HM_FPT; j++) {
-            const int fi = tid + j * HM_TPB;
-            const int tr = tile * 32 + (fi & 31);
-            x.v[j] = (fi < 512 && tr < ntp) ? tp[8 * (long long)tr + ((fi >> 5) & 7)] : 0u;
+            const int fi = tid + j * HM_TPB, sub = fi >> 9, fw = fi & 511;
+            const int tr = (group * HM_TT + sub) * 32 + (fw & 31);
+            x.v[j] = (fi < 512 * HM_TT && tr < ntp) ? tp[8 * (long long)tr + ((fw >> 5) & 7)] : 0u;
         }
         return x;
     };
     auto stage = [&](const Raw& x, int buf) {
 #pragma unroll
         for (int j = 0; j < HM_FPT; j++) {
-            const int fi = tid + j * HM_TPB;
-            if (fi < 512) frag[buf][(fi >> 5) & 7][32 * (fi >> 8) + (fi & 31)] = hm_expand16((x.v[j] >> (16 * (fi >> 8))) & 0xFFFFu, 5);
+            const int fi = tid + j * HM_TPB, sub = fi >> 9, fw = fi & 511;
+            if (fi < 512 * HM_TT) frag[buf][8 * sub + ((fw >> 5) & 7)][32 * (fw >> 8) + (fw & 31)] = hm_expand16((x.v[j] >> (16 * (fw >> 8))) & 0xFFFFu, 5);
         }
     };
     // row words of all trains, once per workgroup
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(HM_TPB, HM_WG_PER_CU * HM_TPB / 256) void k_hamming
     // the sixteen matrix instructions of one tile into `acc`.  The accumulators start from the row words of the tile
     // (C operand of the first k-step: row = train, the same word in every query column), so what comes out IS the key
     //   ((popc(train) + HM_BIAS) << 11 | train) - (2 << 11) <train, query>.
-    auto mma = [&](int tile, int buf, hm_v16i (&acc)[HM_CB]) {
+    auto mma = [&](int tile, int buf, int sub, hm_v16i (&acc)[HM_CB]) {
         hm_v16i wc;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(HM_TPB, HM_WG_PER_CU * HM_TPB / 256) void k_hamming
         }
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            const hm_v4i a = frag[buf][s][lane];
+            const hm_v4i a = frag[buf][8 * sub + s][lane];
 #pragma unroll
             for (int cb = 0; cb < HM_CB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[cb][s], s == 0 ? wc : acc[cb], 0, 0, 0);
         }
@@ -262,18 +266,25 @@ __global__ __launch_bounds__(HM_TPB, HM_WG_PER_CU * HM_TPB / 256) void k_hamming
                 m2[cb] = hm_med3(m1[cb], m2[cb], kx); m1[cb] = min(m1[cb], kx);
             }
     };
+    const int ngroups = (ntiles + HM_TT - 1) / HM_TT;
     Raw nxt = fetch(0);
-    if (ntiles > 0) stage(nxt, 0);
+    if (ngroups > 0) stage(nxt, 0);
     nxt = fetch(1);
     __syncthreads();
-    for (int tile = 0; tile < ntiles; tile++) {
-        const int buf = tile & 1;
-        if (tile + 1 < ntiles) stage(nxt, buf ^ 1);
-        if (tile + 2 < ntiles) nxt = fetch(tile + 2);
+    for (int grp = 0; grp < ngroups; grp++) {
+        const int buf = grp & 1;
+        if (grp + 1 < ngroups) stage(nxt, buf ^ 1);
+        if (grp + 2 < ngroups) nxt = fetch(grp + 2);
         if (wave_live) {
-            hm_v16i acc[HM_CB];
-            mma(tile, buf, acc);
-            fold(acc);
+#pragma unroll
+            for (int sub = 0; sub < HM_TT; sub++) {
+                const int tile = grp * HM_TT + sub;
+                if (tile < ntiles) {
+                    hm_v16i acc[HM_CB];
+                    mma(tile, buf, sub, acc);
+                    fold(acc);
+                }
+            }
         }
         __syncthreads();
     }

@@ -59,8 +59,9 @@ void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc, const 
 int pcg_coarse_dim(int nfree);
 int pcg_coarse_parts(int nfree);
 void pcg_launch_coarse_build(hipStream_t, const double* Hb, const uint8_t* map, const int* id, int nfree, double* Ac);
-void pcg_launch_coarse_mirror(hipStream_t, double* A, int nc);
-void pcg_launch_coarse_identity(hipStream_t, double* A, int nc);
+void pcg_launch_coarse_mirror(hipStream_t, double* A, int ncp);
+void pcg_launch_coarse_invert(hipStream_t, double* A, int ncp, double* D, int* bad);
+int pcg_coarse_pitch(int nfree);
 void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_update(hipStream_t, const BaDev&);
 int ba_scale_blocks(const BaDev&);
@@ -71,9 +72,7 @@ void ba_launch_deactivate(hipStream_t, const BaDev&, const uint8_t* flag);
 
 struct BaState {
     rocblas_handle blas = nullptr;
-    rocblas_handle blas_side = nullptr;    // coarse-level inversion, on `side`, concurrent with the PCG of the current trial
-    hipStream_t side = nullptr;
-    int side_warm_nc = 0;              // coarse size rocSOLVER has been warmed up for
+    hipStream_t side = nullptr;            // coarse-level inversion, concurrent with the PCG of the current trial
     double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
     DevBuf poses, Rt, intr, free_of, pose_of_free, points, edge_pose, edge_point, obs, info, active, err,
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
@@ -86,7 +85,6 @@ void ba_state_free(BaState* s)
     if (!s) return;
     if (s->side) (void)hipStreamSynchronize(s->side);
     if (s->blas) (void)rocblas_destroy_handle(s->blas);
-    if (s->blas_side) (void)rocblas_destroy_handle(s->blas_side);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->pinned) (void)hipHostFree(s->pinned);
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
@@ -334,8 +332,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)n / 192 + 4) * 3 * 8 + 64);
         CCM_RESERVE(c, S.pcg_sc, 64 * 8);
         {
-            const size_t nc = (size_t)pcg_coarse_dim(nfree);
-            CCM_RESERVE(c, S.pcg_aci, nc * nc * 8 + 64); CCM_RESERVE(c, S.pcg_acw, nc * nc * 8 + 64);
+            const size_t nc = (size_t)pcg_coarse_dim(nfree), ncp = (size_t)pcg_coarse_pitch(nfree);
+            CCM_RESERVE(c, S.pcg_aci, ncp * ncp * 8 + 64); CCM_RESERVE(c, S.pcg_acw, (ncp * ncp + 48 * 48) * 8 + 64);   // + one block of scratch
             CCM_RESERVE(c, S.pcg_coarse, ((size_t)n + nc + (size_t)pcg_coarse_parts(nfree) + 64) * 8);    // rcl (<= n), yc, cpart
         }
         CCM_HIP(c, hipGetLastError());
@@ -350,25 +348,10 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // second preconditioner level (ba_sparse.hip): on for systems with at least 64 coarse unknowns
     static const bool want_coarse = !(getenv("CCM_PCG_COARSE") && atoi(getenv("CCM_PCG_COARSE")) == 0);
     PcgCoarse PC{};
-    const int nc = nfree > 0 ? pcg_coarse_dim(nfree) : 0;
+    const int nc = nfree > 0 ? pcg_coarse_dim(nfree) : 0, ncp = nfree > 0 ? pcg_coarse_pitch(nfree) : 0;
     if (use_pcg && want_coarse && nc >= 64) {
         if (!S.side) {
             if (hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess) { S.side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed"); }
-            if (rocblas_create_handle(&S.blas_side) != rocblas_status_success) { S.blas_side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "rocblas_create_handle failed"); }
-            rocblas_set_stream(S.blas_side, S.side);
-            rocblas_set_atomics_mode(S.blas_side, rocblas_atomics_not_allowed);
-            S.side_warm_nc = 0;
-        }
-        if (S.side_warm_nc != nc) {
-            // the first potrf / potri of a size loads rocSOLVER's kernels and sizes its workspace (a quarter of a second):
-            // do that here, on the identity, instead of inside the first trial that starts an inversion
-            CCM_HIP(c, hipMemsetAsync(S.pcg_acw.p, 0, (size_t)nc * nc * 8, S.side));
-            pcg_launch_coarse_identity(S.side, S.pcg_acw.as<double>(), nc);
-            if (rocsolver_dpotrf(S.blas_side, rocblas_fill_lower, nc, S.pcg_acw.as<double>(), nc, S.info_dev.as<int>() + 4) != rocblas_status_success ||
-                rocsolver_dpotri(S.blas_side, rocblas_fill_lower, nc, S.pcg_acw.as<double>(), nc, S.info_dev.as<int>() + 5) != rocblas_status_success)
-                return ccm_fail(c, CCM_E_DEVICE, "rocsolver potrf/potri warm-up failed");
-            CCM_HIP(c, hipStreamSynchronize(S.side));
-            S.side_warm_nc = nc;
         }
         PC.Aci = S.pcg_aci.as<double>();
         PC.rcl = S.pcg_coarse.as<double>();
@@ -490,26 +473,27 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                             side_job.join();
                             if (side_job.status) return ccm_fail(c, CCM_E_DEVICE, "potrf/potri of the coarse matrix failed on the side stream");
                             CCM_HIP(c, hipStreamSynchronize(S.side));                    // the inversion has normally been over for milliseconds
-                            CCM_HIP(c, hipMemcpyAsync(PC.Aci, S.pcg_acw.p, (size_t)nc * nc * 8, hipMemcpyDeviceToDevice, st));
-                            int cinfo[2] = {0, 0};
-                            CCM_HIP(c, hipMemcpyAsync(cinfo, info_dev + 4, 8, hipMemcpyDeviceToHost, st));
+                            CCM_HIP(c, hipMemcpyAsync(PC.Aci, S.pcg_acw.p, (size_t)ncp * ncp * 8, hipMemcpyDeviceToDevice, st));
+                            int cinfo = 0;
+                            CCM_HIP(c, hipMemcpyAsync(&cinfo, info_dev + 4, 4, hipMemcpyDeviceToHost, st));
                             CCM_HIP(c, hipStreamSynchronize(st));
-                            coarse_pending = false; coarse_ready = cinfo[0] == 0 && cinfo[1] == 0;     // a system that was not positive definite leaves no usable inverse
+                            coarse_pending = false; coarse_ready = cinfo == 0;     // a system that was not positive definite leaves no usable inverse
                         }
                         const bool more_trials_planned = it + 1 < iterations || (stage == 0 && opt->iterations2 > 0);
                         if (PC.Aci && more_trials_planned) {
                             double* Aw = S.pcg_acw.as<double>();
-                            pcg_launch_coarse_build(st, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, Aw);   // row-major upper == column-major lower
-                            CCM_HIP(c, hipStreamSynchronize(st));                        // the side stream may start as soon as its kernels are enqueued
+                            pcg_launch_coarse_build(st, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, Aw);
                             BaState* sp = &S;
-                            const int dev = c->device, ncc = nc;
+                            const int dev = c->device, ncc = ncp;
                             int* inf = info_dev;
                             int* status = &side_job.status;
+                            CCM_HIP(c, hipMemsetAsync(inf + 4, 0, 4, st));
+                            CCM_HIP(c, hipStreamSynchronize(st));                        // the side stream may start as soon as its kernels are enqueued
                             side_job.th = std::thread([sp, dev, ncc, Aw, inf, status]() {
                                 int bad_calls = hipSetDevice(dev) != hipSuccess;
-                                bad_calls |= rocsolver_dpotrf(sp->blas_side, rocblas_fill_lower, ncc, Aw, ncc, inf + 4) != rocblas_status_success;
-                                bad_calls |= rocsolver_dpotri(sp->blas_side, rocblas_fill_lower, ncc, Aw, ncc, inf + 5) != rocblas_status_success;
+                                pcg_launch_coarse_invert(sp->side, Aw, ncc, Aw + (size_t)ncc * ncc, inf + 4);
                                 pcg_launch_coarse_mirror(sp->side, Aw, ncc);
+                                bad_calls |= hipGetLastError() != hipSuccess;
                                 *status = bad_calls;
                             });
                             if (!side_thread) side_job.join();

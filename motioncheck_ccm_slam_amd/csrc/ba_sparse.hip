@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, 
 // cluster, but the slowly varying error along the trajectory (many keyframes drifting together) converges only as fast as
 // information travels from cluster to cluster.  The coarse space has 6 unknowns per aggregate of PCG_AGG clusters
 // (one rigid increment shared by the aggregate's keyframes: R sums the 6-vectors of an aggregate), its matrix
-// Ac = R H R^T is dense and small (6 nagg squared), inverted once per LM trial (rocSOLVER potrf + potri), and
+// Ac = R H R^T is dense and small (6 nagg squared), inverted once per LM trial (block Gauss-Jordan below), and
 //   z = Minv r + R^T Ac^-1 R r.
 // Measured on the 2000-keyframe graph (first LM trial, relative residual 1e-8): 345 PCG iterations with the cluster
 // level alone, 137 with 16-keyframe aggregates, 112 with 8-keyframe aggregates.
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, 
 #endif
 #define PCG_AG_KF (PCG_CL * PCG_AGG)
 static_assert(PCG_AG_KF <= 64, "a wave spreads a coarse value over its aggregate's keyframes, one per lane");
-// upper triangle of Ac, row-major (== column-major lower for rocSOLVER): one workgroup per aggregate pair I <= J, thread =
+// upper triangle of Ac, row-major with pitch ncp: one workgroup per aggregate pair I <= J, thread =
 // keyframe pair (i, j), the 36 sums reduced over the workgroup in a fixed order (the ranks of a sharded solve must get
 // the same bits)
 __global__ __launch_bounds__(256) void k_pcg_coarse_build(const double* __restrict__ Hb, const uint8_t* __restrict__ map, const int* __restrict__ id,
-                                                          int nfree, int nagg, double* __restrict__ Ac)
+                                                          int nfree, int nagg, int ncp, double* __restrict__ Ac)
 {
     __shared__ double red[4][36];
     const int I = blockIdx.y, J = blockIdx.x;
@@ -348,21 +348,141 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_build(const double* __restri
     if (threadIdx.x < 36) {
         const int d = threadIdx.x / 6, e = threadIdx.x - 6 * d;
         const int r = 6 * I + d, c = 6 * J + e;
-        if (r <= c) Ac[(long long)r * (6 * nagg) + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        if (r <= c) Ac[(long long)r * ncp + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     }
 }
-// the inverse comes back in the same triangle: fill the other one
-__global__ __launch_bounds__(256) void k_pcg_coarse_mirror(double* __restrict__ A, int nc)
+// Ac was built as an upper triangle: make it the full ncp x ncp matrix the inversion works on (lower from upper, identity
+// in the padding beyond nc)
+__global__ __launch_bounds__(256) void k_pcg_coarse_complete(double* __restrict__ A, int nc, int ncp)
 {
     const long long i = blockIdx.x * 256LL + threadIdx.x;
-    if (i >= (long long)nc * nc) return;
-    const int r = (int)(i / nc), c = (int)(i - (long long)r * nc);
-    if (r > c) A[i] = A[(long long)c * nc + r];
+    if (i >= (long long)ncp * ncp) return;
+    const int r = (int)(i / ncp), c = (int)(i - (long long)r * ncp);
+    if (r >= nc || c >= nc) A[i] = r == c ? 1.0 : 0.0;
+    else if (r > c) A[i] = A[(long long)c * ncp + r];
 }
+// after the inversion: the upper triangle is mirrored so that the preconditioner is exactly symmetric
+__global__ __launch_bounds__(256) void k_pcg_coarse_mirror(double* __restrict__ A, int ncp)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= (long long)ncp * ncp) return;
+    const int r = (int)(i / ncp), c = (int)(i - (long long)r * ncp);
+    if (r > c) A[i] = A[(long long)c * ncp + r];
+}
+
+// ---- dense inverse of the (symmetric positive definite) coarse matrix: in-place block Gauss-Jordan without pivoting,
+// 48 x 48 blocks, four small kernels per block step, every sum in a fixed order -- the result is the same bits on every
+// run and every rank (rocSOLVER's potrf + potri, used here first, differed in the last bits from run to run).
+//   D = A_kk^-1;  A_kj <- D A_kj (j != k);  A_ij <- A_ij - A_ik A_kj (i, j != k);  A_ik <- -A_ik D (i != k);  A_kk <- D
+#define INV_B 48
+#define INV_T 3                  // a thread of the 16 x 16 workgroup owns INV_T x INV_T outputs of a block
+static_assert(INV_B == 16 * INV_T, "256 threads tile a block");
+// D = A_kk^-1 by in-place Gauss-Jordan in LDS
+__global__ __launch_bounds__(256) void k_inv_diag(const double* __restrict__ A, int lda, int k, double* __restrict__ D, int* __restrict__ bad)
+{
+    __shared__ double a[INV_B][INV_B];
+    __shared__ double fcol[INV_B], prow[INV_B];
+    const double* Akk = A + ((long long)k * INV_B) * lda + (long long)k * INV_B;
+    for (int i = threadIdx.x; i < INV_B * INV_B; i += 256) a[i / INV_B][i % INV_B] = Akk[(long long)(i / INV_B) * lda + i % INV_B];
+    __syncthreads();
+    bool ok = true;
+    for (int p = 0; p < INV_B; p++) {
+        const double piv = a[p][p];
+        if (!(piv > 0.0)) ok = false;
+        const double ip = 1.0 / piv;
+        if (threadIdx.x < INV_B) { fcol[threadIdx.x] = a[threadIdx.x][p]; prow[threadIdx.x] = ((int)threadIdx.x == p ? 1.0 : a[p][threadIdx.x]) * ip; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < INV_B * INV_B; e += 256) {
+            const int i = e / INV_B, j = e - i * INV_B;
+            a[i][j] = i == p ? prow[j] : ((j == p ? 0.0 : a[i][j]) - fcol[i] * prow[j]);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < INV_B * INV_B; i += 256) D[i] = a[i / INV_B][i % INV_B];
+    if (!ok && threadIdx.x == 0) atomicOr(bad, 1);
+}
+// C (one block, in registers: thread = INV_T x INV_T outputs) = X Y with X, Y staged in LDS; k ascending
+__device__ __forceinline__ void inv_mm(const double (*X)[INV_B], const double (*Y)[INV_B], double (&c)[INV_T][INV_T])
+{
+    const int tr = INV_T * (threadIdx.x >> 4), tc = INV_T * (threadIdx.x & 15);
+#pragma unroll
+    for (int i = 0; i < INV_T; i++)
+#pragma unroll
+        for (int j = 0; j < INV_T; j++) c[i][j] = 0.0;
+    for (int kk = 0; kk < INV_B; kk++) {
+        double x[INV_T], y[INV_T];
+#pragma unroll
+        for (int i = 0; i < INV_T; i++) { x[i] = X[tr + i][kk]; y[i] = Y[kk][tc + i]; }
+#pragma unroll
+        for (int i = 0; i < INV_T; i++)
+#pragma unroll
+            for (int j = 0; j < INV_T; j++) c[i][j] += x[i] * y[j];
+    }
+}
+__device__ __forceinline__ void inv_load(double (*T)[INV_B], const double* __restrict__ src, int ld)
+{
+    for (int i = threadIdx.x; i < INV_B * INV_B; i += 256) { const int r = i / INV_B, c = i - r * INV_B; T[r][c] = src[(long long)r * ld + c]; }
+}
+// mode 0: A_kj <- D A_kj (block column j = blockIdx.x, skipping k);  mode 1: A_ik <- -A_ik D (block row i = blockIdx.x, skipping k; the
+// extra last workgroup stores A_kk <- D);  mode 2: A_ij <- A_ij - A_ik A_kj (i = blockIdx.y, j = blockIdx.x, both skipping k)
+__global__ __launch_bounds__(256) void k_inv_step(double* __restrict__ A, int lda, int nblk, int k, const double* __restrict__ D, int mode)
+{
+    __shared__ double X[INV_B][INV_B], Y[INV_B][INV_B];
+    const int tr = INV_T * (threadIdx.x >> 4), tc = INV_T * (threadIdx.x & 15);
+    auto blk = [&](int bi, int bj) { return A + ((long long)bi * INV_B) * lda + (long long)bj * INV_B; };
+    double c[INV_T][INV_T];
+    if (mode == 1 && (int)blockIdx.x == nblk - 1) {                    // A_kk <- D
+        double* K = blk(k, k);
+        for (int i = threadIdx.x; i < INV_B * INV_B; i += 256) K[(long long)(i / INV_B) * lda + i % INV_B] = D[i];
+        return;
+    }
+    const int bx = (int)blockIdx.x + ((int)blockIdx.x >= k ? 1 : 0);
+    if (mode == 0) {
+        double* T = blk(k, bx);
+        inv_load(X, D, INV_B); inv_load(Y, T, lda);
+        __syncthreads();
+        inv_mm(X, Y, c);
+#pragma unroll
+        for (int i = 0; i < INV_T; i++)
+#pragma unroll
+            for (int j = 0; j < INV_T; j++) T[(long long)(tr + i) * lda + tc + j] = c[i][j];
+    } else if (mode == 1) {
+        double* T = blk(bx, k);
+        inv_load(X, T, lda); inv_load(Y, D, INV_B);
+        __syncthreads();
+        inv_mm(X, Y, c);
+#pragma unroll
+        for (int i = 0; i < INV_T; i++)
+#pragma unroll
+            for (int j = 0; j < INV_T; j++) T[(long long)(tr + i) * lda + tc + j] = -c[i][j];
+    } else {
+        const int by = (int)blockIdx.y + ((int)blockIdx.y >= k ? 1 : 0);
+        double* T = blk(by, bx);
+        inv_load(X, blk(by, k), lda); inv_load(Y, blk(k, bx), lda);
+        __syncthreads();
+        inv_mm(X, Y, c);
+#pragma unroll
+        for (int i = 0; i < INV_T; i++)
+#pragma unroll
+            for (int j = 0; j < INV_T; j++) T[(long long)(tr + i) * lda + tc + j] -= c[i][j];
+    }
+}
+// in-place inverse of the ncp x ncp matrix A (ncp a multiple of INV_B); D = one block of scratch; *bad is raised on a non-positive pivot
+void pcg_launch_coarse_invert(hipStream_t s, double* A, int ncp, double* D, int* bad)
+{
+    const int nb = ncp / INV_B;
+    for (int k = 0; k < nb; k++) {
+        hipLaunchKernelGGL(k_inv_diag, dim3(1), dim3(256), 0, s, A, ncp, k, D, bad);
+        if (nb > 1) hipLaunchKernelGGL(k_inv_step, dim3(nb - 1), dim3(256), 0, s, A, ncp, nb, k, D, 0);
+        if (nb > 1) hipLaunchKernelGGL(k_inv_step, dim3(nb - 1, nb - 1), dim3(256), 0, s, A, ncp, nb, k, D, 2);
+        hipLaunchKernelGGL(k_inv_step, dim3(nb), dim3(256), 0, s, A, ncp, nb, k, D, 1);
+    }
+}
+
 // yc = Ac^-1 (R r), z += R^T yc: rcl holds the per-cluster sums of the residual (written by k_pcg_init / k_pcg_update), a
 // wave per coarse row (aggregate I, component d) which then adds its value to component d of the aggregate's keyframes;
 // cpart[workgroup] = the workgroup's share of (R r) . yc, which is the coarse level's contribution to r.z
-__global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ Aci, int nc, const double* __restrict__ rcl, int ncl,
+__global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ Aci, int nc, int ncp, const double* __restrict__ rcl, int ncl,
                                                     double* __restrict__ yc, double* __restrict__ cpart, double* __restrict__ z, int nfree)
 {
     extern __shared__ double rc[];
@@ -378,7 +498,7 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wv;
     double s = 0;
     if (row < nc) {
-        const double* A = Aci + (long long)row * nc;
+        const double* A = Aci + (long long)row * ncp;
         for (int c = lane; c < nc; c += 64) s += A[c] * rc[c];
     }
     for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
@@ -673,26 +793,23 @@ hipError_t pcg_launch_minv(hipStream_t s, const double* Hb, const int* blk_row, 
 }
 // coarse level: sizes, set-up (Ac into `Ac`, upper triangle row-major; the caller factors and inverts it, then mirrors)
 int pcg_coarse_dim(int nfree) { return 6 * nblk(nfree, PCG_AG_KF); }
+int pcg_coarse_pitch(int nfree) { return nblk(pcg_coarse_dim(nfree), INV_B) * INV_B; }
 int pcg_coarse_parts(int nfree) { return nblk(pcg_coarse_dim(nfree), 4); }
+// Ac = R H R^T as a full (padded) matrix in `Ac`
 void pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, double* Ac)
 {
-    const int nagg = nblk(nfree, PCG_AG_KF);
-    hipLaunchKernelGGL(k_pcg_coarse_build, dim3(nagg, nagg), dim3(256), 0, s, Hb, map, id, nfree, nagg, Ac);
+    const int nagg = nblk(nfree, PCG_AG_KF), nc = 6 * nagg, ncp = pcg_coarse_pitch(nfree);
+    hipLaunchKernelGGL(k_pcg_coarse_build, dim3(nagg, nagg), dim3(256), 0, s, Hb, map, id, nfree, nagg, ncp, Ac);
+    hipLaunchKernelGGL(k_pcg_coarse_complete, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, Ac, nc, ncp);
 }
-void pcg_launch_coarse_mirror(hipStream_t s, double* A, int nc)
+void pcg_launch_coarse_mirror(hipStream_t s, double* A, int ncp)
 {
-    hipLaunchKernelGGL(k_pcg_coarse_mirror, dim3(nblk((long long)nc * nc, 256)), dim3(256), 0, s, A, nc);
+    hipLaunchKernelGGL(k_pcg_coarse_mirror, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, A, ncp);
 }
-__global__ __launch_bounds__(256) void k_pcg_coarse_identity(double* __restrict__ A, int nc)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nc) A[(long long)i * nc + i] = 1.0;
-}
-void pcg_launch_coarse_identity(hipStream_t s, double* A, int nc) { hipLaunchKernelGGL(k_pcg_coarse_identity, dim3(nblk(nc, 256)), dim3(256), 0, s, A, nc); }
 static void pcg_launch_coarse(hipStream_t s, const PcgCoarse& C, int nfree, double* w)
 {
     const int nc = pcg_coarse_dim(nfree);
-    hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, C.rcl, nblk(nfree, PCG_CL), C.yc, C.cpart,
+    hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, pcg_coarse_pitch(nfree), C.rcl, nblk(nfree, PCG_CL), C.yc, C.cpart,
                        w + 2 * 6LL * nfree, nfree);
 }
 void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C)

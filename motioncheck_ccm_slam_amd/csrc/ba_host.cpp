@@ -73,6 +73,7 @@ void ba_launch_deactivate(hipStream_t, const BaDev&, const uint8_t* flag);
 struct BaState {
     rocblas_handle blas = nullptr;
     hipStream_t side = nullptr;            // coarse-level inversion, concurrent with the PCG of the current trial
+    hipEvent_t ev_hb = nullptr;            // the side stream has finished reading the reduced system
     double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
     DevBuf poses, Rt, intr, free_of, pose_of_free, points, edge_pose, edge_point, obs, info, active, err,
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
@@ -85,6 +86,7 @@ void ba_state_free(BaState* s)
     if (!s) return;
     if (s->side) (void)hipStreamSynchronize(s->side);
     if (s->blas) (void)rocblas_destroy_handle(s->blas);
+    if (s->ev_hb) (void)hipEventDestroy(s->ev_hb);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->pinned) (void)hipHostFree(s->pinned);
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
@@ -352,6 +354,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     if (use_pcg && want_coarse && nc >= 64) {
         if (!S.side) {
             if (hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess) { S.side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed"); }
+            CCM_HIP(c, hipEventCreateWithFlags(&S.ev_hb, hipEventDisableTiming));
         }
         PC.Aci = S.pcg_aci.as<double>();
         PC.rcl = S.pcg_coarse.as<double>();
@@ -386,6 +389,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         }
     }
     static const bool side_thread = !(getenv("CCM_PCG_SIDE_THREAD") && atoi(getenv("CCM_PCG_SIDE_THREAD")) == 0);
+    bool hb_in_use = false;                                // the side stream is still reading this trial's reduced system
     bool coarse_ready = false, coarse_pending = false;     // an inverse is in Aci / an inversion is running on the side stream
     // rocSOLVER spends about two milliseconds of HOST time enqueuing the kernels of one potrf + potri; a helper thread does
     // that while this thread keeps the PCG of the current trial going.  Joined before the next trial looks at the result.
@@ -471,7 +475,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         // trial uses depends only on the trial number, never on timing, so all ranks do the same.
                         if (PC.Aci && coarse_pending) {
                             side_job.join();
-                            if (side_job.status) return ccm_fail(c, CCM_E_DEVICE, "potrf/potri of the coarse matrix failed on the side stream");
+                            if (side_job.status) return ccm_fail(c, CCM_E_DEVICE, "the inversion of the coarse matrix could not be launched on the side stream");
                             CCM_HIP(c, hipStreamSynchronize(S.side));                    // the inversion has normally been over for milliseconds
                             CCM_HIP(c, hipMemcpyAsync(PC.Aci, S.pcg_acw.p, (size_t)ncp * ncp * 8, hipMemcpyDeviceToDevice, st));
                             int cinfo = 0;
@@ -482,13 +486,16 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         const bool more_trials_planned = it + 1 < iterations || (stage == 0 && opt->iterations2 > 0);
                         if (PC.Aci && more_trials_planned) {
                             double* Aw = S.pcg_acw.as<double>();
-                            pcg_launch_coarse_build(st, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, Aw);
+                            // the reduced system is final (synchronised above); the side stream assembles Ac from it, and this
+                            // thread waits for that event before the next trial overwrites Hb
                             BaState* sp = &S;
                             const int dev = c->device, ncc = ncp;
                             int* inf = info_dev;
                             int* status = &side_job.status;
-                            CCM_HIP(c, hipMemsetAsync(inf + 4, 0, 4, st));
-                            CCM_HIP(c, hipStreamSynchronize(st));                        // the side stream may start as soon as its kernels are enqueued
+                            CCM_HIP(c, hipMemsetAsync(inf + 4, 0, 4, S.side));
+                            pcg_launch_coarse_build(S.side, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, Aw);
+                            CCM_HIP(c, hipEventRecord(S.ev_hb, S.side));
+                            hb_in_use = true;
                             side_job.th = std::thread([sp, dev, ncc, Aw, inf, status]() {
                                 int bad_calls = hipSetDevice(dev) != hipSuccess;
                                 pcg_launch_coarse_invert(sp->side, Aw, ncc, Aw + (size_t)ncc * ncc, inf + 4);
@@ -556,6 +563,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     t2 = clk::now();
                     res->t_schur += secs(t1, t2);
                 }
+                if (hb_in_use) { CCM_HIP(c, hipEventSynchronize(S.ev_hb)); hb_in_use = false; }     // long over: the assembly is the side stream's first 0.2 ms
                 if (ranks > 1 && nfree > 0) {
                     // Every rank has solved the same reduced system, but rocSOLVER's factorisations (dense path, coarse
                     // preconditioner) are only reproducible to rounding.  Rank 0's increment -- and its verdict on positive

@@ -487,6 +487,13 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
 {
     extern __shared__ double rc[];
     __shared__ double dots[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wv;
+    // the row of the inverse is requested first: its latency passes under the assembly of R r
+    constexpr int PRE = 24;                                   // 64 * 24 = 1536 columns in registers, the rest (larger maps) afterwards
+    double av[PRE];
+    const double* A = Aci + (long long)min(row, nc - 1) * ncp;
+#pragma unroll
+    for (int q = 0; q < PRE; q++) { const int c = lane + 64 * q; av[q] = c < nc ? A[c] : 0.0; }
     for (int i = threadIdx.x; i < nc; i += 256) {
         const int I = i / 6, d = i - 6 * I;
         double s = 0;
@@ -495,11 +502,11 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
         rc[i] = s;
     }
     __syncthreads();
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wv;
     double s = 0;
     if (row < nc) {
-        const double* A = Aci + (long long)row * ncp;
-        for (int c = lane; c < nc; c += 64) s += A[c] * rc[c];
+#pragma unroll
+        for (int q = 0; q < PRE; q++) { const int c = lane + 64 * q; if (c < nc) s += av[q] * rc[c]; }
+        for (int c = lane + 64 * PRE; c < nc; c += 64) s += A[c] * rc[c];
     }
     for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
     if (row < nc && lane < PCG_AG_KF) {

@@ -170,7 +170,8 @@ print("ok")
     for rc, o, e in outs:
         assert rc == 0 and o.strip().endswith("ok"), o[-1500:] + e[-1500:]
     a, b = np.load(files[0]), np.load(files[1])
-    assert (a["poses"] == b["poses"]).all() and (a["points"] == b["points"]).all(), "the ranks disagree on the result"
+    assert (a["poses"] == b["poses"]).all() and (a["points"] == b["points"]).all(), \
+        "the ranks disagree on the result: max |d poses| %.3e, max |d points| %.3e" % (np.abs(a["poses"] - b["poses"]).max(), np.abs(a["points"] - b["points"]).max())
     assert int(a["pairs"]) > 0 and int(b["pairs"]) > 0 and int(a["pairs"]) != int(b["pairs"])      # each rank enumerated its own share
 
 

@@ -145,21 +145,25 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double*
     }
 }
 
-// One wave per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Y_a W_b^T
+// One workgroup per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Y_a W_b^T
 // with Y_a = Hpl_a Dinv (6x3) and W_b = Hpl_b (6x3).  The sum over pairs is one GEMM with K = 3 x pairs:
 // [Y_a1 Y_a2 ...] (6 x K) times [W_b1 W_b2 ...]^T (K x 6), run on the f64 matrix cores as v_mfma_f64_16x16x4_f64
 // (M = N = 16 of which 6 are used, K = 4 per instruction: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]).
-// Four pairs = twelve k = three MFMAs per step (eight pairs per step measured slower); each lane gathers exactly the operand elements its (row, k) needs,
-// so nothing goes through LDS.  The accumulation order is the hardware's fixed k order: reproducible run to run.
+// Four pairs = twelve k = three MFMAs per step (eight pairs per step measured slower); each lane gathers exactly the operand
+// elements its (row, k) needs, so the operands never go through LDS.  The four waves of the workgroup take every fourth step
+// (a keyframe's diagonal block has as many pairs as the keyframe has observations: one wave per block left a 0.5 ms tail),
+// and a wave requests the pair indices two steps and the operands one step ahead of the MFMAs that use them (a step used to
+// cost two dependent memory round trips).  The accumulation order -- the hardware's k order inside a wave, wave 0..3 at the
+// end -- is fixed: reproducible run to run.
 typedef double sp_v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                                                          const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb,
                                                          double* __restrict__ Hb)
 {
+    __shared__ double part[4][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wv;
-    if (b >= nb) return;
+    const int b = blockIdx.x;
     const int i = lane & 15, kq = lane >> 4;                // operand row (< 6 used), k within an MFMA
     const int p0 = seg_start[b], p1 = seg_end[b];
     sp_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
@@ -167,31 +171,47 @@ __global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* 
     int pl[3], cl[3];
 #pragma unroll
     for (int m = 0; m < 3; m++) { const int kk = 4 * m + kq; pl[m] = kk / 3; cl[m] = kk - 3 * pl[m]; }
-    for (int p = p0; p < p1; p += 4) {
-        double av[3], bv[3];
+    const unsigned long long NONE = ~0ull;
+    auto ld_idx = [&](int p, unsigned long long (&pr)[3]) {
+#pragma unroll
+        for (int m = 0; m < 3; m++) pr[m] = (i < 6 && p + pl[m] < p1) ? pairs[p + pl[m]] : NONE;
+    };
+    auto ld_ops = [&](const unsigned long long (&pr)[3], double (&av)[3], double (&bv)[3]) {
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             av[m] = 0.0; bv[m] = 0.0;
-            if (i < 6 && p + pl[m] < p1) {
-                const unsigned long long pr = pairs[p + pl[m]];
-                av[m] = Y[18 * (long long)(unsigned)(pr >> 32) + 3 * i + cl[m]];
-                bv[m] = D.Hpl[18 * (long long)(unsigned)(pr & 0xFFFFFFFFu) + 3 * i + cl[m]];
+            if (pr[m] != NONE) {
+                av[m] = Y[18 * (long long)(unsigned)(pr[m] >> 32) + 3 * i + cl[m]];
+                bv[m] = D.Hpl[18 * (long long)(unsigned)(pr[m] & 0xFFFFFFFFu) + 3 * i + cl[m]];
             }
         }
+    };
+    unsigned long long pr_next[3], pr_far[3];
+    double av[3], bv[3], av_next[3], bv_next[3];
+    int p = p0 + 4 * wv;                                    // this wave's steps: 4 pairs each, 16 pairs apart
+    ld_idx(p, pr_next); ld_ops(pr_next, av, bv); ld_idx(p + 16, pr_next);
+    for (; p < p1; p += 16) {
+        ld_ops(pr_next, av_next, bv_next);
+        ld_idx(p + 32, pr_far);
 #pragma unroll
         for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[m], acc, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 3; m++) { av[m] = av_next[m]; bv[m] = bv_next[m]; pr_next[m] = pr_far[m]; }
     }
     // C/D: column = lane & 15, row = (lane >> 4) + 4 * reg
     const int c = lane & 15;
-    if (c >= 6) return;
-    const int rb = blk_row[b], cb = blk_col[b];
+    if (c < 6) {
 #pragma unroll
-    for (int reg = 0; reg < 2; reg++) {
-        const int r = kq + 4 * reg;
-        if (r < 6) {
-            const double base = rb == cb ? D.Hpp[36 * (long long)rb + 6 * r + c] : 0.0;
-            Hb[36 * (long long)b + 6 * r + c] = base - acc[reg];
+        for (int reg = 0; reg < 2; reg++) {
+            const int r = kq + 4 * reg;
+            if (r < 6) part[wv][6 * r + c] = acc[reg];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int rb = blk_row[b], cb = blk_col[b];
+        const double base = rb == cb ? D.Hpp[36 * (long long)rb + threadIdx.x] : 0.0;
+        Hb[36 * (long long)b + threadIdx.x] = base - (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
     }
 }
 
@@ -237,6 +257,9 @@ __global__ __launch_bounds__(256) void k_sp_to_dense(const double* __restrict__ 
 // off-diagonal blocks of the reduced camera system); its inverse is a dense PCG_CN x PCG_CN matrix per cluster, applied
 // as a mat-vec.  Minv layout: [cluster][PCG_CN][PCG_CN], symmetric.
 #define PCG_CL 8
+#ifndef PCG_XCDS
+#define PCG_XCDS 8               // 1 = block rows in dispatch order (round-robin over the XCDs)
+#endif
 #define PCG_CN (6 * PCG_CL)
 __global__ __launch_bounds__(256) void k_pcg_cl_gather(const double* __restrict__ Hb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                                        int nb, double* __restrict__ Mc)
@@ -589,7 +612,12 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
 {
     __shared__ double red[42][6];
     __shared__ double s_beta;
-    const int row = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs, so b and b + 8 share an L2.  Giving each XCD a contiguous range of
+    // block rows means that block (i, j) of the band, needed by row i and (transposed) by row j a few rows later, is
+    // fetched from the fabric once and found in that XCD's L2 the second time.
+    const int rows_per_xcd = (nfree + PCG_XCDS - 1) / PCG_XCDS;
+    const int row = ((int)blockIdx.x % PCG_XCDS) * rows_per_xcd + (int)blockIdx.x / PCG_XCDS;
+    if (row >= nfree) return;
     const long long n = 6LL * nfree;
     if (threadIdx.x < 64) {
         double rz = 0, rr = 0;
@@ -781,7 +809,7 @@ void sp_launch_dinv(hipStream_t s, const BaDev& D, double lambda, double* Y, dou
 { if (D.L > 0) hipLaunchKernelGGL(k_sp_dinv, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, lambda, Y, db); }
 void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, const unsigned long long* pairs, const int* st, const int* en,
                             const int* br, const int* bc, int nb, double* Hb)
-{ hipLaunchKernelGGL(k_sp_schur_blocks, dim3(nblk(nb, 4)), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb); }
+{ if (nb > 0) hipLaunchKernelGGL(k_sp_schur_blocks, dim3(nb), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb); }
 void sp_launch_bschur(hipStream_t s, const BaDev& D, const double* db, double* bs)
 { if (D.nfree > 0) hipLaunchKernelGGL(k_sp_bschur, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, db, bs); }
 void sp_launch_add_lambda(hipStream_t s, const int* diag, int nfree, double lambda, double* Hb)
@@ -832,7 +860,7 @@ void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const 
 {
     const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
     const int ncp = C.Aci ? pcg_coarse_parts(nfree) : 0;
-    hipLaunchKernelGGL(k_pcg_spmv, dim3(nfree), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity,
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(PCG_XCDS * nblk(nfree, PCG_XCDS)), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity,
                        C.cpart, ncp);
     hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity, C.Aci ? C.rcl : nullptr);
     if (C.Aci) pcg_launch_coarse(s, C, nfree, w);

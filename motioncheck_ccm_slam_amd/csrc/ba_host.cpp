@@ -12,7 +12,6 @@
 #include "ccm_internal.h"
 #include "ba_types.h"
 #include "ba_math.h"
-#include <rocsolver/rocsolver.h>
 #include <thread>
 #include <algorithm>
 #include <cfloat>
@@ -62,6 +61,8 @@ void pcg_launch_coarse_build(hipStream_t, const double* Hb, const uint8_t* map, 
 void pcg_launch_coarse_mirror(hipStream_t, double* A, int ncp);
 void pcg_launch_coarse_invert(hipStream_t, double* A, int ncp, double* D, int* bad);
 int pcg_coarse_pitch(int nfree);
+int dense_pitch(long long n);
+void dense_launch_solve(hipStream_t, double* A, int n, int lda, const double* b, double* x, int* bad);
 void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_update(hipStream_t, const BaDev&);
 int ba_scale_blocks(const BaDev&);
@@ -71,7 +72,6 @@ void ba_launch_outliers(hipStream_t, const BaDev&, double th, uint8_t* flag);
 void ba_launch_deactivate(hipStream_t, const BaDev&, const uint8_t* flag);
 
 struct BaState {
-    rocblas_handle blas = nullptr;
     hipStream_t side = nullptr;            // coarse-level inversion, concurrent with the PCG of the current trial
     hipEvent_t ev_hb = nullptr;            // the side stream has finished reading the reduced system
     double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
@@ -85,7 +85,6 @@ void ba_state_free(BaState* s)
 {
     if (!s) return;
     if (s->side) (void)hipStreamSynchronize(s->side);
-    if (s->blas) (void)rocblas_destroy_handle(s->blas);
     if (s->ev_hb) (void)hipEventDestroy(s->ev_hb);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->pinned) (void)hipHostFree(s->pinned);
@@ -174,11 +173,6 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     CCM_HIP(c, hipSetDevice(c->device));
     if (!c->ba) c->ba = new BaState();
     BaState& S = *c->ba;
-    if (!S.blas) {
-        if (rocblas_create_handle(&S.blas) != rocblas_status_success) { S.blas = nullptr; return ccm_fail(c, CCM_E_DEVICE, "rocblas_create_handle failed"); }
-        rocblas_set_stream(S.blas, c->stream);
-        rocblas_set_atomics_mode(S.blas, rocblas_atomics_not_allowed);   // the ranks of a sharded solve must compute the same bits
-    }
     if (!S.pinned && hipHostMalloc((void**)&S.pinned, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         S.pinned = nullptr;
         return ccm_fail(c, CCM_E_NOMEM, "hipHostMalloc failed");
@@ -351,7 +345,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     static const bool want_coarse = !(getenv("CCM_PCG_COARSE") && atoi(getenv("CCM_PCG_COARSE")) == 0);
     PcgCoarse PC{};
     const int nc = nfree > 0 ? pcg_coarse_dim(nfree) : 0, ncp = nfree > 0 ? pcg_coarse_pitch(nfree) : 0;
-    if (use_pcg && want_coarse && nc >= 64) {
+    if (use_pcg && want_coarse && nc >= 64 && nc <= 2304) {      // beyond: the cubic inversion would outlast an LM trial (more than 24 576 free keyframes)
         if (!S.side) {
             if (hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess) { S.side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed"); }
             CCM_HIP(c, hipEventCreateWithFlags(&S.ev_hb, hipEventDisableTiming));
@@ -540,20 +534,18 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         if (!solved) res->pcg_fallbacks++;
                     }
                     if (!solved) {
-                        CCM_RESERVE(c, S.Hs, ((size_t)n * n + 8) * 8);
+                        // dense solve by the in-house block Gauss-Jordan (see dense_launch_solve for why not rocSOLVER)
+                        const size_t npd = (size_t)dense_pitch(n);
+                        CCM_RESERVE(c, S.Hs, (npd * npd + 48 * 48 + 8) * 8);
                         double* Hs = S.Hs.as<double>();
-                        CCM_HIP(c, hipMemsetAsync(Hs, 0, (size_t)n * n * 8, st));
-                        sp_launch_to_dense(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, n, Hs);
-                        CCM_HIP(c, hipMemcpyAsync(D.x, D.bs, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-                        // row-major upper block triangle == column-major lower triangle
-                        if (rocsolver_dpotrf(S.blas, rocblas_fill_lower, (rocblas_int)n, Hs, (rocblas_int)n, info_dev) != rocblas_status_success)
-                            return ccm_fail(c, CCM_E_DEVICE, "rocsolver_dpotrf failed");
+                        CCM_HIP(c, hipMemsetAsync(Hs, 0, npd * npd * 8, st));
+                        CCM_HIP(c, hipMemsetAsync(info_dev, 0, 4, st));
+                        sp_launch_to_dense(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, (long long)npd, Hs);   // row-major upper block triangle, pitch npd
+                        dense_launch_solve(st, Hs, (int)n, (int)npd, D.bs, D.x, info_dev);
                         int info = 0;
                         CCM_HIP(c, hipMemcpyAsync(&info, info_dev, 4, hipMemcpyDeviceToHost, st));
                         CCM_HIP(c, hipStreamSynchronize(st));
                         ok2 = info == 0;
-                        if (ok2 && rocsolver_dpotrs(S.blas, rocblas_fill_lower, (rocblas_int)n, 1, Hs, (rocblas_int)n, D.x, (rocblas_int)n) != rocblas_status_success)
-                            return ccm_fail(c, CCM_E_DEVICE, "rocsolver_dpotrs failed");
                     }
                     CCM_HIP(c, hipStreamSynchronize(st));
                 } else {

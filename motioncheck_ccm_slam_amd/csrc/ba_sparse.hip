@@ -317,17 +317,25 @@ __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, 
 
 // Second level of the preconditioner (additive two-level Schwarz): the cluster inverses above damp the error inside a
 // cluster, but the slowly varying error along the trajectory (many keyframes drifting together) converges only as fast as
-// information travels from cluster to cluster.  The coarse space has 6 unknowns per aggregate of PCG_AGG clusters
+// information travels from cluster to cluster.  The coarse space has 6 unknowns per aggregate of pcg_agg_clusters() clusters
 // (one rigid increment shared by the aggregate's keyframes: R sums the 6-vectors of an aggregate), its matrix
 // Ac = R H R^T is dense and small (6 nagg squared), inverted once per LM trial (block Gauss-Jordan below), and
 //   z = Minv r + R^T Ac^-1 R r.
 // Measured on the 2000-keyframe graph (first LM trial, relative residual 1e-8): 345 PCG iterations with the cluster
 // level alone, 137 with 16-keyframe aggregates, 112 with 8-keyframe aggregates.
 #ifndef PCG_AGG
-#define PCG_AGG 2
+#define PCG_AGG 2                // clusters per aggregate up to PCG_COARSE_MAX coarse unknowns; doubled beyond (at most 8)
 #endif
-#define PCG_AG_KF (PCG_CL * PCG_AGG)
-static_assert(PCG_AG_KF <= 64, "a wave spreads a coarse value over its aggregate's keyframes, one per lane");
+#define PCG_COARSE_MAX 1536
+// clusters per aggregate for a map of `nfree` free keyframes: the smallest of PCG_AGG, 2 PCG_AGG, ... (<= 8: a wave spreads a
+// coarse value over its aggregate's keyframes, one per lane) that keeps the coarse system within PCG_COARSE_MAX unknowns
+// (its inversion is cubic and has to fit inside one LM trial)
+__host__ __device__ inline int pcg_agg_clusters(int nfree)
+{
+    int agg = PCG_AGG;
+    while (agg < 8 && 6 * ((nfree + PCG_CL * agg - 1) / (PCG_CL * agg)) > PCG_COARSE_MAX) agg *= 2;
+    return agg < 8 ? agg : 8;
+}
 // upper triangle of Ac, row-major with pitch ncp: one workgroup per aggregate pair I <= J, thread =
 // keyframe pair (i, j), the 36 sums reduced over the workgroup in a fixed order (the ranks of a sharded solve must get
 // the same bits)
@@ -337,8 +345,9 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_build(const double* __restri
     __shared__ double red[4][36];
     const int I = blockIdx.y, J = blockIdx.x;
     if (J < I) return;
-    const int i0 = I * PCG_AG_KF, j0 = J * PCG_AG_KF;
-    const int ni = min(PCG_AG_KF, nfree - i0), nj = min(PCG_AG_KF, nfree - j0);
+    const int ag_kf = PCG_CL * pcg_agg_clusters(nfree);
+    const int i0 = I * ag_kf, j0 = J * ag_kf;
+    const int ni = min(ag_kf, nfree - i0), nj = min(ag_kf, nfree - j0);
     double acc[36];
 #pragma unroll
     for (int e = 0; e < 36; e++) acc[e] = 0.0;
@@ -490,6 +499,17 @@ __global__ __launch_bounds__(256) void k_inv_step(double* __restrict__ A, int ld
             for (int j = 0; j < INV_T; j++) T[(long long)(tr + i) * lda + tc + j] -= c[i][j];
     }
 }
+// y = A x for a dense row-major n x n matrix of pitch lda: a wave per row, lanes stride the columns, fixed butterfly
+__global__ __launch_bounds__(256) void k_dense_matvec(const double* __restrict__ A, int n, int lda, const double* __restrict__ x, double* __restrict__ y)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const double* a = A + (long long)row * lda;
+    double s = 0;
+    for (int c = lane; c < n; c += 64) s += a[c] * x[c];
+    for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
+    if (lane == 0) y[row] = s;
+}
 // in-place inverse of the ncp x ncp matrix A (ncp a multiple of INV_B); D = one block of scratch; *bad is raised on a non-positive pivot
 void pcg_launch_coarse_invert(hipStream_t s, double* A, int ncp, double* D, int* bad)
 {
@@ -510,6 +530,7 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
 {
     extern __shared__ double rc[];
     __shared__ double dots[4];
+    const int agg = pcg_agg_clusters(nfree);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wv;
     // the row of the inverse is requested first: its latency passes under the assembly of R r
     constexpr int PRE = 24;                                   // 64 * 24 = 1536 columns in registers, the rest (larger maps) afterwards
@@ -521,7 +542,7 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
         const int I = i / 6, d = i - 6 * I;
         double s = 0;
 #pragma unroll
-        for (int a = 0; a < PCG_AGG; a++) { const int cl = I * PCG_AGG + a; if (cl < ncl) s += rcl[6 * cl + d]; }
+        for (int a = 0; a < agg; a++) { const int cl = I * agg + a; if (cl < ncl) s += rcl[6 * cl + d]; }
         rc[i] = s;
     }
     __syncthreads();
@@ -532,8 +553,8 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
         for (int c = lane + 64 * PRE; c < nc; c += 64) s += A[c] * rc[c];
     }
     for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
-    if (row < nc && lane < PCG_AG_KF) {
-        const int I = row / 6, kf = I * PCG_AG_KF + lane;
+    if (row < nc && lane < PCG_CL * agg) {
+        const int I = row / 6, kf = I * PCG_CL * agg + lane;
         if (kf < nfree) z[6LL * kf + (row - 6 * I)] += s;
     }
     if (lane == 0) { if (row < nc) yc[row] = s; dots[wv] = row < nc ? s * rc[row] : 0.0; }
@@ -827,13 +848,13 @@ hipError_t pcg_launch_minv(hipStream_t s, const double* Hb, const int* blk_row, 
     return hipSuccess;
 }
 // coarse level: sizes, set-up (Ac into `Ac`, upper triangle row-major; the caller factors and inverts it, then mirrors)
-int pcg_coarse_dim(int nfree) { return 6 * nblk(nfree, PCG_AG_KF); }
+int pcg_coarse_dim(int nfree) { return 6 * nblk(nfree, PCG_CL * pcg_agg_clusters(nfree)); }
 int pcg_coarse_pitch(int nfree) { return nblk(pcg_coarse_dim(nfree), INV_B) * INV_B; }
 int pcg_coarse_parts(int nfree) { return nblk(pcg_coarse_dim(nfree), 4); }
 // Ac = R H R^T as a full (padded) matrix in `Ac`
 void pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, double* Ac)
 {
-    const int nagg = nblk(nfree, PCG_AG_KF), nc = 6 * nagg, ncp = pcg_coarse_pitch(nfree);
+    const int nagg = nblk(nfree, PCG_CL * pcg_agg_clusters(nfree)), nc = 6 * nagg, ncp = pcg_coarse_pitch(nfree);
     hipLaunchKernelGGL(k_pcg_coarse_build, dim3(nagg, nagg), dim3(256), 0, s, Hb, map, id, nfree, nagg, ncp, Ac);
     hipLaunchKernelGGL(k_pcg_coarse_complete, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, Ac, nc, ncp);
 }
@@ -871,3 +892,15 @@ void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc, cons
     hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nblk(6LL * nfree, PCG_UPD_TPB), part, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
 }
 
+int dense_pitch(long long n) { return (int)((n + INV_B - 1) / INV_B) * INV_B; }
+// Dense solve of the reduced system (small maps; fallback of the PCG): A (upper block triangle, row-major, pitch lda = dense_pitch(n),
+// followed by one INV_B x INV_B block of scratch) is completed, inverted in place by the block Gauss-Jordan above and applied
+// to b.  No library call: rocSOLVER's potrf / potrs return wrong factors (relative errors up to 1e-2, tools/dbg_potrf.py)
+// whenever another process or stream keeps the GPU busy at the same time, and are exact only when they run alone.
+void dense_launch_solve(hipStream_t s, double* A, int n, int lda, const double* b, double* x, int* bad)
+{
+    hipLaunchKernelGGL(k_pcg_coarse_complete, dim3(nblk((long long)lda * lda, 256)), dim3(256), 0, s, A, n, lda);
+    pcg_launch_coarse_invert(s, A, lda, A + (size_t)lda * lda, bad);
+    hipLaunchKernelGGL(k_pcg_coarse_mirror, dim3(nblk((long long)lda * lda, 256)), dim3(256), 0, s, A, lda);
+    hipLaunchKernelGGL(k_dense_matvec, dim3(nblk(n, 4)), dim3(256), 0, s, A, n, lda, b, x);
+}

@@ -895,8 +895,9 @@ void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc, cons
 int dense_pitch(long long n) { return (int)((n + INV_B - 1) / INV_B) * INV_B; }
 // Dense solve of the reduced system (small maps; fallback of the PCG): A (upper block triangle, row-major, pitch lda = dense_pitch(n),
 // followed by one INV_B x INV_B block of scratch) is completed, inverted in place by the block Gauss-Jordan above and applied
-// to b.  No library call: rocSOLVER's potrf / potrs return wrong factors (relative errors up to 1e-2, tools/dbg_potrf.py)
-// whenever another process or stream keeps the GPU busy at the same time, and are exact only when they run alone.
+// to b.  No library call: rocSOLVER's potrf / potrs returned wrong solutions (relative errors up to 1e-2, tools/dbg_potrf.py)
+// whenever a second process factored on the same GPU at the same time, and differed in the last bits from run to run next to
+// this library's own side stream; they were exact and repeatable only when they ran alone.
 void dense_launch_solve(hipStream_t s, double* A, int n, int lda, const double* b, double* x, int* bad)
 {
     hipLaunchKernelGGL(k_pcg_coarse_complete, dim3(nblk((long long)lda * lda, 256)), dim3(256), 0, s, A, n, lda);

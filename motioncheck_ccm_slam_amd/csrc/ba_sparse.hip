@@ -133,15 +133,22 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double*
     db[3 * (long long)l] = Di[0] * b0 + Di[1] * b1 + Di[2] * b2;
     db[3 * (long long)l + 1] = Di[3] * b0 + Di[4] * b1 + Di[5] * b2;
     db[3 * (long long)l + 2] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
-    for (int e = D.pt_first[l]; e < D.pt_first[l + 1]; e++) {
-        const double* B = D.Hpl + 18 * (long long)e;
-        double* y = Y + 18 * (long long)e;
-        for (int i = 0; i < 6; i++) {
-            const double x = B[i * 3], yy = B[i * 3 + 1], z = B[i * 3 + 2];
-            y[i * 3] = x * Di[0] + yy * Di[3] + z * Di[6];
-            y[i * 3 + 1] = x * Di[1] + yy * Di[4] + z * Di[7];
-            y[i * 3 + 2] = x * Di[2] + yy * Di[5] + z * Di[8];
-        }
+}
+// per edge: Y_e = Hpl_e Dinv(landmark of e)  (one thread per edge: nine times the parallelism of a loop inside k_sp_dinv)
+__global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double* __restrict__ Y)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= D.E) return;
+    const double* Di = D.Dinv + 9 * (long long)D.edge_point[e];
+    const double d0 = Di[0], d1 = Di[1], d2 = Di[2], d3 = Di[3], d4 = Di[4], d5 = Di[5], d6 = Di[6], d7 = Di[7], d8 = Di[8];
+    const double* B = D.Hpl + 18 * (long long)e;
+    double* y = Y + 18 * (long long)e;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double x = B[i * 3], yy = B[i * 3 + 1], z = B[i * 3 + 2];
+        y[i * 3] = x * d0 + yy * d3 + z * d6;
+        y[i * 3 + 1] = x * d1 + yy * d4 + z * d7;
+        y[i * 3 + 2] = x * d2 + yy * d5 + z * d8;
     }
 }
 
@@ -827,7 +834,10 @@ void sp_launch_row_entries(hipStream_t s, const int* br, const int* bc, int nb, 
 void sp_launch_row_ptr(hipStream_t s, const unsigned* skey, int n_ent, int nfree, int* row_ptr)
 { hipLaunchKernelGGL(k_sp_row_ptr, dim3(nblk(n_ent, 256)), dim3(256), 0, s, skey, n_ent, nfree, row_ptr); }
 void sp_launch_dinv(hipStream_t s, const BaDev& D, double lambda, double* Y, double* db)
-{ if (D.L > 0) hipLaunchKernelGGL(k_sp_dinv, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, lambda, Y, db); }
+{
+    if (D.L > 0) hipLaunchKernelGGL(k_sp_dinv, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, lambda, Y, db);
+    if (D.E > 0) hipLaunchKernelGGL(k_sp_edge_y, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, Y);
+}
 void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, const unsigned long long* pairs, const int* st, const int* en,
                             const int* br, const int* bc, int nb, double* Hb)
 { if (nb > 0) hipLaunchKernelGGL(k_sp_schur_blocks, dim3(nb), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb); }

@@ -357,29 +357,31 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     }
     // The PCG inner loop is two small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
-    const int pcg_chunk = 16;                     // even: the r.z slot parity is the same at the start of every chunk
-    // Two graphs: the cluster level alone (first trial of a call: no coarse inverse exists yet) and both levels.
+    // Chunk lengths (even: the r.z slot parity is the same at the start of every chunk): 16 iterations per host round trip
+    // while far from the tolerance, 4 near the end, chosen from the contraction observed so far.
+    const int pcg_len[2] = {16, 4};
+    // Graphs: [level][length]; level 0 = the cluster level alone (first trial of a call: no coarse inverse exists yet), 1 = both levels.
     PcgCoarse PC0{};
-    hipGraph_t pcg_graph[2] = {nullptr, nullptr}; hipGraphExec_t pcg_exec[2] = {nullptr, nullptr};
-    struct GraphGuard { hipGraph_t* g; hipGraphExec_t* e; ~GraphGuard() { for (int i = 0; i < 2; i++) { if (e[i]) (void)hipGraphExecDestroy(e[i]); if (g[i]) (void)hipGraphDestroy(g[i]); } } } graph_guard{pcg_graph, pcg_exec};
+    hipGraph_t pcg_graph[4] = {nullptr, nullptr, nullptr, nullptr}; hipGraphExec_t pcg_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+    struct GraphGuard { hipGraph_t* g; hipGraphExec_t* e; ~GraphGuard() { for (int i = 0; i < 4; i++) { if (e[i]) (void)hipGraphExecDestroy(e[i]); if (g[i]) (void)hipGraphDestroy(g[i]); } } } graph_guard{pcg_graph, pcg_exec};
     if (use_pcg && nfree > 0) {
         CCM_HIP(c, hipStreamSynchronize(st));
-        for (int lv = 0; lv < (PC.Aci ? 2 : 1); lv++) {
-            const PcgCoarse& pc = lv ? PC : PC0;
+        for (int gi = 0; gi < (PC.Aci ? 4 : 2); gi++) {
+            const PcgCoarse& pc = (gi >> 1) ? PC : PC0;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                for (int k = 0; k < pcg_chunk; k++)
+                for (int k = 0; k < pcg_len[gi & 1]; k++)
                     pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
                                     nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pc);
                 pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pc);
-                hipError_t e1 = hipStreamEndCapture(st, &pcg_graph[lv]);
-                hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec[lv], pcg_graph[lv], nullptr, nullptr, 0) : e1;
+                hipError_t e1 = hipStreamEndCapture(st, &pcg_graph[gi]);
+                hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec[gi], pcg_graph[gi], nullptr, nullptr, 0) : e1;
                 if (e2 != hipSuccess) {
-                    pcg_exec[lv] = nullptr;                     // fall back to plain launches
+                    pcg_exec[gi] = nullptr;                     // fall back to plain launches
                     if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph capture failed: %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
                     (void)hipGetLastError();
                 }
             } else { if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] hipStreamBeginCapture failed\n"); (void)hipGetLastError(); }
-            if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph %d %s\n", lv, pcg_exec[lv] ? "ready" : "not used");
+            if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph %d %s\n", gi, pcg_exec[gi] ? "ready" : "not used");
         }
     }
     static const bool side_thread = !(getenv("CCM_PCG_SIDE_THREAD") && atoi(getenv("CCM_PCG_SIDE_THREAD")) == 0);
@@ -501,14 +503,15 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                             coarse_pending = true;
                         }
                         const PcgCoarse& pcu = coarse_ready ? PC : PC0;
-                        hipGraphExec_t gexec = pcg_exec[coarse_ready ? 1 : 0];
+                        const int glv = coarse_ready ? 2 : 0;
                         pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                         const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
                         static const double env_tol = getenv("CCM_PCG_TOL") ? atof(getenv("CCM_PCG_TOL")) : 0.0;
                         const double pcg_tol = env_tol > 0 ? env_tol : (opt->pcg_tol > 0 ? opt->pcg_tol : 1e-8);   // relative residual
                         const double tol2 = pcg_tol * pcg_tol;
                         volatile double* sc = S.pinned;
-                        int itc = 0, badh = 0;
+                        int itc = 0, badh = 0, last_len = 0;
+                        double rr_prev = 0;
                         CCM_HIP(c, hipMemcpyAsync(&badh, bad, 4, hipMemcpyDeviceToHost, st));
                         for (;;) {
                             CCM_HIP(c, hipMemcpyAsync(S.pinned, S.pcg_sc.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -516,17 +519,26 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                             if (badh || !(sc[3] > 0.0) || !std::isfinite(sc[2])) { ok2 = 0; solved = true; break; }   // not positive definite
                             if (sc[2] <= tol2 * sc[1]) { solved = true; break; }
                             if (itc >= max_it) break;
-                            const int reps = (itc < 64 && !coarse_ready) ? 2 : 1;       // few host round trips while far from convergence
-                            for (int rpt = 0; rpt < reps; rpt++) {
+                            // iterations still needed if |r|^2 keeps contracting as over the last round trip; without an estimate
+                            // (first round trip, stagnation) or far from the tolerance: full chunks
+                            const double rr = sc[2], target = tol2 * sc[1];
+                            int launches = (itc < 64 && !coarse_ready) ? 2 : 1, which = 0;
+                            if (last_len > 0 && rr_prev > 0 && rr < rr_prev) {
+                                const double need = std::log(rr / target) / (std::log(rr_prev / rr) / last_len);
+                                if (need <= 12.0) { which = 1; launches = std::max(1, (int)std::ceil(need / pcg_len[1])); }
+                            }
+                            rr_prev = rr; last_len = launches * pcg_len[which];
+                            hipGraphExec_t gexec = pcg_exec[glv + which];
+                            for (int rpt = 0; rpt < launches; rpt++) {
                                 if (gexec) CCM_HIP(c, hipGraphLaunch(gexec, st));
                                 else {
-                                    for (int k = 0; k < pcg_chunk; k++)
+                                    for (int k = 0; k < pcg_len[which]; k++)
                                         pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
                                                         nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pcu);
                                     pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                                 }
                             }
-                            itc += reps * pcg_chunk;
+                            itc += last_len;
                         }
                         res->pcg_iterations += itc;
                         if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms, rel.res %.2e\n", itc, secs(t2, clk::now()) * 1e3, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)));

@@ -339,7 +339,7 @@ typedef struct {
     int32_t schur_blocks;     /* non-zero 6x6 blocks (upper triangle) */
     int64_t schur_pairs;      /* (landmark, pose-pair) contributions on this rank */
     int32_t pcg_iterations;   /* conjugate-gradient iterations, all trials (0 on the dense path) */
-    int32_t pcg_fallbacks;    /* trials that fell back to the dense Cholesky */
+    int32_t pcg_fallbacks;    /* trials that fell back to the dense solve */
 } ccm_ba_result;
 
 int ccm_ba_solve(ccm_ctx*, ccm_ba_problem*, const ccm_ba_options*, ccm_ba_result*);

@@ -5,9 +5,9 @@
 //   SparseOptimizer::optimize            cslam/thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-419
 //   OptimizationAlgorithmLevenberg::solve  .../core/optimization_algorithm_levenberg.cpp:61-189
 //   BlockSolver<6,3>::buildSystem/solve  .../core/block_solver.hpp:354-486, 502-604
-// The reduced camera system is solved by dense Cholesky (rocSOLVER potrf/potrs) in place of
-// LinearSolverEigen's SimplicialLDLT (solvers/linear_solver_eigen.h:106-136): any exact SPD solve is
-// equivalent up to rounding.  With an RCCL communicator attached (ccm_comm_init) the landmarks are
+// The reduced camera system is solved by a dense inverse (in-house block Gauss-Jordan, ba_sparse.hip) for small maps and
+// by a two-level preconditioned CG on the packed blocks for large ones, in place of LinearSolverEigen's SimplicialLDLT
+// (solvers/linear_solver_eigen.h:106-136): any SPD solve of sufficient accuracy is equivalent up to rounding.  With an RCCL communicator attached (ccm_comm_init) the landmarks are
 // sharded over the ranks and the reduced system is summed with one all-reduce per LM trial.
 #include "ccm_internal.h"
 #include "ba_types.h"
@@ -338,7 +338,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     double* Hb = S.Hb.as<double>();
     D.bs = nfree > 0 ? Hb + 36 * (size_t)nb : nullptr;
     res->schur_blocks = nb; res->schur_pairs = NP;
-    // dense Cholesky for small systems (exact, and cheaper than PCG start-up), PCG on the packed blocks otherwise
+    // dense solve for small systems (exact, and cheaper than PCG start-up), PCG on the packed blocks otherwise
     static const int dense_max = getenv("CCM_BA_DENSE_MAX") ? atoi(getenv("CCM_BA_DENSE_MAX")) : 1536;
     const bool use_pcg = n > dense_max;
     // second preconditioner level (ba_sparse.hip): on for systems with at least 64 coarse unknowns
@@ -387,8 +387,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     static const bool side_thread = !(getenv("CCM_PCG_SIDE_THREAD") && atoi(getenv("CCM_PCG_SIDE_THREAD")) == 0);
     bool hb_in_use = false;                                // the side stream is still reading this trial's reduced system
     bool coarse_ready = false, coarse_pending = false;     // an inverse is in Aci / an inversion is running on the side stream
-    // rocSOLVER spends about two milliseconds of HOST time enqueuing the kernels of one potrf + potri; a helper thread does
-    // that while this thread keeps the PCG of the current trial going.  Joined before the next trial looks at the result.
+    // The inversion of the coarse matrix is 66 small launches; a helper thread enqueues them while this thread keeps the PCG
+    // of the current trial going.  Joined before the next trial looks at the result.
     struct SideJob { std::thread th; int status = 0; void join() { if (th.joinable()) th.join(); } ~SideJob() { join(); } } side_job;
 
     auto stop_requested = [&]() { return opt->stop_flag && *opt->stop_flag; };
@@ -569,10 +569,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 }
                 if (hb_in_use) { CCM_HIP(c, hipEventSynchronize(S.ev_hb)); hb_in_use = false; }     // long over: the assembly is the side stream's first 0.2 ms
                 if (ranks > 1 && nfree > 0) {
-                    // Every rank has solved the same reduced system, but rocSOLVER's factorisations (dense path, coarse
-                    // preconditioner) are only reproducible to rounding.  Rank 0's increment -- and its verdict on positive
-                    // definiteness -- is the one all ranks apply, so their poses stay bit-identical: the others contribute zeros
-                    // to a sum all-reduce (x + 0 is exact).
+                    // Every rank has solved the same reduced system.  Rank 0's increment -- and its verdict on positive
+                    // definiteness -- is the one all ranks apply, so their poses stay bit-identical whatever a rank's solver
+                    // did: the others contribute zeros to a sum all-reduce (x + 0 is exact).
                     double* flag = scal + 3;
                     S.pinned[12] = (rank == 0 && ok2) ? 1.0 : 0.0;
                     CCM_HIP(c, hipMemcpyAsync(flag, S.pinned + 12, 8, hipMemcpyHostToDevice, st));

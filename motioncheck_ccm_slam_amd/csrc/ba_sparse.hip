@@ -12,7 +12,7 @@
 // The reduced system is solved by block-Jacobi preconditioned conjugate gradients on the packed blocks
 // (stand-in for LinearSolverEigen's sparse LDLT, solvers/linear_solver_eigen.h:106-136; converged to a
 // relative residual of 1e-13 it agrees with the exact solve far below the 1e-5 pose tolerance); small
-// systems and non-converging ones are scattered into a dense array and go to rocSOLVER's Cholesky.
+// systems and non-converging ones are scattered into a dense array and go to the dense solve at the end of this file.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string.h>
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_sp_add_lambda(const int* __restrict__ d
     Hb[36 * (long long)diag_id[f] + 7 * r] += lambda;
 }
 
-// packed blocks -> dense row-major n x n (upper block triangle), for the Cholesky path
+// packed blocks -> dense row-major n x n (upper block triangle), for the dense path
 __global__ __launch_bounds__(256) void k_sp_to_dense(const double* __restrict__ Hb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                                      int nb, long long n, double* __restrict__ Hs)
 {

@@ -143,8 +143,8 @@ print("ok")
 def test_sharded_gba_two_ranks_on_one_gpu(dense_max, tmp_path):
     """Multi-GPU global BA rehearsed on one GPU: two processes = two ranks, each keeps the landmarks of its range,
     the partial reduced camera systems are summed through the shared-memory transport (RCCL's place).  Both ranks must
-    return the same poses and points, and they must agree with the CPU oracle.  dense_max 0 = PCG, large = rocSOLVER
-    Cholesky; the solve is replicated and rank 0's increment is the one every rank applies (one small all-reduce per
+    return the same poses and points, and they must agree with the CPU oracle.  dense_max 0 = PCG, large = the dense
+    solve; the solve is replicated and rank 0's increment is the one every rank applies (one small all-reduce per
     trial), so the ranks are bit-identical with either solver."""
     import subprocess, sys, uuid
     code = r'''

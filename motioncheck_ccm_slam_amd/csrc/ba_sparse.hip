@@ -287,18 +287,17 @@ __global__ __launch_bounds__(256) void k_pcg_cl_gather(const double* __restrict_
     M[cc * PCG_CN + rr] = v;
 }
 // in-place inverse of every cluster matrix by Gauss-Jordan without pivoting (SPD); unused rows of the last cluster
-// are made identity; a non-positive pivot raises `bad`
+// are made identity; a non-positive pivot raises `bad`.  The matrix is overwritten column by column with its inverse
+// (the same arithmetic as eliminating [A | I], without storing the half that is known to be 0 / 1).
 __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, int nfree, int* __restrict__ bad)
 {
-    // augmented [A | I] -> [I | A^-1]; column 2*PCG_CN+... padding of 1 keeps the row stride odd (bank conflicts)
-    __shared__ double a[PCG_CN][2 * PCG_CN + 1];
-    __shared__ double fcol[PCG_CN];
+    __shared__ double a[PCG_CN][PCG_CN + 1];                 // + 1: odd row stride (bank conflicts on column reads)
+    __shared__ double fcol[PCG_CN], prow[PCG_CN];
     double* M = Mc + (long long)blockIdx.x * PCG_CN * PCG_CN;
     const int used = 6 * min(PCG_CL, nfree - (int)blockIdx.x * PCG_CL);
     for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 256) {
         const int r = i / PCG_CN, c = i - r * PCG_CN;
         a[r][c] = (r < used && c < used) ? M[i] : (r == c ? 1.0 : 0.0);
-        a[r][PCG_CN + c] = r == c ? 1.0 : 0.0;
     }
     __syncthreads();
     bool ok = true;
@@ -306,19 +305,15 @@ __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, 
         const double piv = a[k][k];
         if (!(piv > 0.0)) ok = false;
         const double ip = 1.0 / piv;
-        if (threadIdx.x < PCG_CN) fcol[threadIdx.x] = a[threadIdx.x][k];
-        __syncthreads();                                         // everyone has read the pivot and the pivot column
-        // row k is scaled on the fly: a[i][j] -= a[i][k] * (a[k][j] / piv); row k itself becomes a[k][j] / piv
-        for (int e = threadIdx.x; e < PCG_CN * 2 * PCG_CN; e += 256) {
-            const int i = e / (2 * PCG_CN), j = e - i * 2 * PCG_CN;
-            const double rk = a[k][j] * ip;
-            if (i != k) a[i][j] -= fcol[i] * rk;
+        if (threadIdx.x < PCG_CN) { fcol[threadIdx.x] = a[threadIdx.x][k]; prow[threadIdx.x] = ((int)threadIdx.x == k ? 1.0 : a[k][threadIdx.x]) * ip; }
+        __syncthreads();                                         // everyone has read the pivot, the pivot row and the pivot column
+        for (int e = threadIdx.x; e < PCG_CN * PCG_CN; e += 256) {
+            const int i = e / PCG_CN, j = e - i * PCG_CN;
+            a[i][j] = i == k ? prow[j] : ((j == k ? 0.0 : a[i][j]) - fcol[i] * prow[j]);
         }
         __syncthreads();
-        for (int j = threadIdx.x; j < 2 * PCG_CN; j += 256) a[k][j] *= ip;
-        __syncthreads();
     }
-    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 256) M[i] = a[i / PCG_CN][PCG_CN + i % PCG_CN];
+    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 256) M[i] = a[i / PCG_CN][i % PCG_CN];
     if (!ok && threadIdx.x == 0) atomicOr(bad, 1);
 }
 

@@ -12,7 +12,6 @@
 #include "ccm_internal.h"
 #include "ba_types.h"
 #include "ba_math.h"
-#include <thread>
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
@@ -384,12 +383,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
             if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph %d %s\n", gi, pcg_exec[gi] ? "ready" : "not used");
         }
     }
-    static const bool side_thread = !(getenv("CCM_PCG_SIDE_THREAD") && atoi(getenv("CCM_PCG_SIDE_THREAD")) == 0);
     bool hb_in_use = false;                                // the side stream is still reading this trial's reduced system
     bool coarse_ready = false, coarse_pending = false;     // an inverse is in Aci / an inversion is running on the side stream
-    // The inversion of the coarse matrix is 66 small launches; a helper thread enqueues them while this thread keeps the PCG
-    // of the current trial going.  Joined before the next trial looks at the result.
-    struct SideJob { std::thread th; int status = 0; void join() { if (th.joinable()) th.join(); } ~SideJob() { join(); } } side_job;
 
     auto stop_requested = [&]() { return opt->stop_flag && *opt->stop_flag; };
     // chi2 (+ optionally scale) of the current state, summed over ranks
@@ -470,8 +465,6 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         // factor, H by one relinearisation); this trial's system starts the next inversion.  Which inverse a
                         // trial uses depends only on the trial number, never on timing, so all ranks do the same.
                         if (PC.Aci && coarse_pending) {
-                            side_job.join();
-                            if (side_job.status) return ccm_fail(c, CCM_E_DEVICE, "the inversion of the coarse matrix could not be launched on the side stream");
                             CCM_HIP(c, hipStreamSynchronize(S.side));                    // the inversion has normally been over for milliseconds
                             CCM_HIP(c, hipMemcpyAsync(PC.Aci, S.pcg_acw.p, (size_t)ncp * ncp * 8, hipMemcpyDeviceToDevice, st));
                             int cinfo = 0;
@@ -480,28 +473,22 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                             coarse_pending = false; coarse_ready = cinfo == 0;     // a system that was not positive definite leaves no usable inverse
                         }
                         const bool more_trials_planned = it + 1 < iterations || (stage == 0 && opt->iterations2 > 0);
-                        if (PC.Aci && more_trials_planned) {
+                        // The next inversion (assembly of Ac from this trial's system, block Gauss-Jordan: 68 small launches, 0.2 ms
+                        // of host time) goes to the side stream right after this trial's first chunk of PCG iterations has been
+                        // launched, so the host enqueues it while the GPU is already iterating.
+                        bool side_todo = PC.Aci && more_trials_planned;
+                        auto start_inversion = [&]() -> int {
                             double* Aw = S.pcg_acw.as<double>();
-                            // the reduced system is final (synchronised above); the side stream assembles Ac from it, and this
-                            // thread waits for that event before the next trial overwrites Hb
-                            BaState* sp = &S;
-                            const int dev = c->device, ncc = ncp;
-                            int* inf = info_dev;
-                            int* status = &side_job.status;
-                            CCM_HIP(c, hipMemsetAsync(inf + 4, 0, 4, S.side));
+                            CCM_HIP(c, hipMemsetAsync(info_dev + 4, 0, 4, S.side));
                             pcg_launch_coarse_build(S.side, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, Aw);
-                            CCM_HIP(c, hipEventRecord(S.ev_hb, S.side));
+                            CCM_HIP(c, hipEventRecord(S.ev_hb, S.side));                 // awaited before the next trial overwrites Hb
                             hb_in_use = true;
-                            side_job.th = std::thread([sp, dev, ncc, Aw, inf, status]() {
-                                int bad_calls = hipSetDevice(dev) != hipSuccess;
-                                pcg_launch_coarse_invert(sp->side, Aw, ncc, Aw + (size_t)ncc * ncc, inf + 4);
-                                pcg_launch_coarse_mirror(sp->side, Aw, ncc);
-                                bad_calls |= hipGetLastError() != hipSuccess;
-                                *status = bad_calls;
-                            });
-                            if (!side_thread) side_job.join();
-                            coarse_pending = true;
-                        }
+                            pcg_launch_coarse_invert(S.side, Aw, ncp, Aw + (size_t)ncp * ncp, info_dev + 4);
+                            pcg_launch_coarse_mirror(S.side, Aw, ncp);
+                            CCM_HIP(c, hipGetLastError());
+                            coarse_pending = true; side_todo = false;
+                            return CCM_OK;
+                        };
                         const PcgCoarse& pcu = coarse_ready ? PC : PC0;
                         const int glv = coarse_ready ? 2 : 0;
                         pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
@@ -539,7 +526,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                                 }
                             }
                             itc += last_len;
+                            if (side_todo && (rc = start_inversion())) return rc;
                         }
+                        if (side_todo && (rc = start_inversion())) return rc;
                         res->pcg_iterations += itc;
                         if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms, rel.res %.2e\n", itc, secs(t2, clk::now()) * 1e3, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)));
                         if (solved && ok2) CCM_HIP(c, hipMemcpyAsync(D.x, S.pcg_w.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
@@ -615,7 +604,6 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         }
     }
 
-    side_job.join();
     if (S.side) CCM_HIP(c, hipStreamSynchronize(S.side));
     // ---- results
     CCM_HIP(c, hipMemcpyAsync(pb->poses, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToHost, st));

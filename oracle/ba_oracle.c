@@ -13,8 +13,11 @@
  *   cslam/thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-435
  *   src/Optimizer.cpp:536-602 (local BA's two-stage schedule), src/Converter.cc:40-119
  * Eigen (Quaterniond(R), 3x3 inverse, SimplicialLDLT) is not in the tree: its
- * arithmetic is restated; the reduced system is solved by dense Cholesky, any
- * exact SPD solve being equivalent up to rounding.  Edge
+ * arithmetic is restated; the reduced system is solved by dense Cholesky on small
+ * graphs and by the block-sparse Cholesky of bchol_oracle.c (minimum-degree ordering
+ * once, exact factorisation per trial: linear_solver_eigen.h:106-136,165-222) above
+ * ORC_SPARSE_MIN_FREE free keyframes, any exact SPD solve being equivalent up to
+ * rounding.  Edge
  * summation order here is edge-array order; g2o's depends on pointer-ordered
  * maps, so bitwise equality with g2o is impossible by construction and the
  * contract is a tolerance (1e-5 on pose updates).  PARITY UNPINNED vs g2o.
@@ -188,6 +191,9 @@ typedef struct {
     double* Hll; double* bl;           /* [L][9], [L][3] */
     double* Hpl;                       /* [E][18] (6x3), zero for fixed / inactive */
     double* Hs; double* bs;            /* dense 6nfree x 6nfree, 6nfree */
+    int sparse;                        /* reduced system held block-sparse + bchol_oracle.c instead of dense Hs */
+    int32_t* sidx; double* sblk; int nsblk;   /* [nfree*nfree] (f1 <= f2) -> slot, [nsblk][36] upper blocks of Hschur */
+    orc_bchol* chol;
     double* x;                         /* [6nfree + 3L] */
     double* Dinv; double* coeff;
     int* pt_first; int* pt_edges;      /* CSR landmark -> edges (sorted by pose) */
@@ -344,15 +350,72 @@ static void schur_reduce(ba_t* s, double lambda)
     for (int i = 0; i < n; i++) s->bs[i] = s->bp[i] - s->coeff[i];
 }
 
+/* The same reduction into the block-sparse upper triangle (f1 <= f2) of Hschur: identical products in the identical
+ * order, only the destination differs. */
+static void schur_reduce_sparse(ba_t* s, double lambda)
+{
+    const int n = 6 * s->nfree, nf = s->nfree;
+    memset(s->sblk, 0, sizeof(double) * 36 * (size_t)s->nsblk);
+    memset(s->coeff, 0, sizeof(double) * n);
+    for (int f = 0; f < nf; f++) {
+        double* Hd = s->sblk + 36 * (size_t)s->sidx[(size_t)f * nf + f];
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++)
+            Hd[i * 6 + j] = s->Hpp[36 * (size_t)f + i * 6 + j] + (i == j ? lambda : 0.0);
+    }
+    for (int l = 0; l < s->L; l++) {
+        double D[9], db[3];
+        memcpy(D, s->Hll + 9 * (size_t)l, sizeof D);
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        double* Di = s->Dinv + 9 * (size_t)l;
+        inv3(D, Di);
+        const double* b_l = s->bl + 3 * (size_t)l;
+        for (int i = 0; i < 3; i++) db[i] = Di[i * 3] * b_l[0] + Di[i * 3 + 1] * b_l[1] + Di[i * 3 + 2] * b_l[2];
+        for (int a = s->pt_first[l]; a < s->pt_first[l + 1]; a++) {
+            const int e1 = s->pt_edges[a];
+            const int f1 = s->free_of[s->pb->edge_pose[e1]];
+            if (f1 < 0 || !s->active[e1]) continue;
+            const double* Bi = s->Hpl + 18 * (size_t)e1;
+            double BD[18];
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++)
+                BD[i * 3 + j] = Bi[i * 3] * Di[j] + Bi[i * 3 + 1] * Di[3 + j] + Bi[i * 3 + 2] * Di[6 + j];
+            for (int i = 0; i < 6; i++)
+                s->coeff[6 * f1 + i] += Bi[i * 3] * db[0] + Bi[i * 3 + 1] * db[1] + Bi[i * 3 + 2] * db[2];
+            for (int b = a; b < s->pt_first[l + 1]; b++) {
+                const int e2 = s->pt_edges[b];
+                const int f2 = s->free_of[s->pb->edge_pose[e2]];
+                if (f2 < 0 || !s->active[e2]) continue;
+                const double* Bj = s->Hpl + 18 * (size_t)e2;
+                /* edges of a landmark are sorted by pose, so f1 <= f2; a pose repeated inside one landmark (f1 == f2,
+                 * a != b; the synthetic graphs have none) adds the product and its transpose to the diagonal block */
+                double* T = s->sblk + 36 * (size_t)s->sidx[(size_t)f1 * nf + f2];
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+                    const double v = BD[i * 3] * Bj[j * 3] + BD[i * 3 + 1] * Bj[j * 3 + 1] + BD[i * 3 + 2] * Bj[j * 3 + 2];
+                    T[i * 6 + j] -= v;
+                    if (f1 == f2 && a != b) T[j * 6 + i] -= v;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < n; i++) s->bs[i] = s->bp[i] - s->coeff[i];
+}
+
 /* solve with the current lambda; x = [poses | landmarks]; returns 0 if the reduced system is not SPD */
 static int schur_solve(ba_t* s, double lambda)
 {
     const int n = 6 * s->nfree;
+    if (s->sparse) {
+        schur_reduce_sparse(s, lambda);
+        if (n > 0) {
+            if (orc_bchol_factor(s->chol, s->sidx, s->sblk) <= 0) return 0;
+            orc_bchol_solve(s->chol, s->bs, s->x);
+        }
+    } else {
     schur_reduce(s, lambda);
     if (n > 0) {
         if (!chol_factor(s->Hs, n)) return 0;
         memcpy(s->x, s->bs, sizeof(double) * n);
         chol_solve(s->Hs, n, s->x);
+    }
     }
     /* landmarks: xl = Dinv (bl - Hpl^T xp)  (block_solver.hpp:461-481) */
     for (int l = 0; l < s->L; l++) {
@@ -381,7 +444,15 @@ static int cmp_edge_pose(const void* a, const void* b, void* ctx)
     return x < y ? -1 : (x > y);
 }
 
-static ba_t* ba_new(orc_ba_problem* pb)
+/* 0 = automatic (block-sparse above ORC_SPARSE_MIN_FREE free keyframes), 1 = dense, 2 = block-sparse.  Test hook. */
+#define ORC_SPARSE_MIN_FREE 400
+static int g_solver_mode = 0;
+void orc_ba_set_solver(int mode) { g_solver_mode = mode; }
+
+static ba_t* ba_new_mode(orc_ba_problem* pb, int mode);
+static ba_t* ba_new(orc_ba_problem* pb) { return ba_new_mode(pb, g_solver_mode); }
+
+static ba_t* ba_new_mode(orc_ba_problem* pb, int mode)
 {
     ba_t* s = (ba_t*)calloc(1, sizeof(ba_t));
     s->pb = pb; s->P = pb->n_poses; s->L = pb->n_points; s->E = pb->n_edges;
@@ -397,7 +468,8 @@ static ba_t* ba_new(orc_ba_problem* pb)
     s->Hll = (double*)malloc(sizeof(double) * 9 * (size_t)(s->L + 1));
     s->bl = (double*)malloc(sizeof(double) * 3 * (size_t)(s->L + 1));
     s->Hpl = (double*)malloc(sizeof(double) * 18 * (size_t)(s->E + 1));
-    s->Hs = (double*)malloc(sizeof(double) * ((size_t)n * n + 1));
+    s->sparse = mode == 2 || (mode == 0 && s->nfree > ORC_SPARSE_MIN_FREE);
+    s->Hs = (double*)malloc(sizeof(double) * (s->sparse ? 1 : (size_t)n * n + 1));
     s->bs = (double*)malloc(sizeof(double) * (n + 1));
     s->x = (double*)calloc((size_t)n + 3 * (size_t)s->L + 1, sizeof(double));
     s->Dinv = (double*)malloc(sizeof(double) * 9 * (size_t)(s->L + 1));
@@ -413,13 +485,37 @@ static ba_t* ba_new(orc_ba_problem* pb)
         qsort_r(s->pt_edges + s->pt_first[l], s->pt_first[l + 1] - s->pt_first[l], sizeof(int),
                 cmp_edge_pose, (void*)pb->edge_pose);
     free(fill);
+    if (s->sparse && s->nfree > 0) {
+        /* BlockSolver::buildStructure (block_solver.hpp:143-295): the pattern of Hschur is the diagonal plus one block per
+         * pair of free keyframes sharing a landmark, whatever the edges' activity */
+        const int nf = s->nfree;
+        uint8_t* adj = (uint8_t*)calloc((size_t)nf * nf + 1, 1);
+        for (int f = 0; f < nf; f++) adj[(size_t)f * nf + f] = 1;
+        for (int l = 0; l < s->L; l++)
+            for (int a = s->pt_first[l]; a < s->pt_first[l + 1]; a++) {
+                const int f1 = s->free_of[pb->edge_pose[s->pt_edges[a]]];
+                if (f1 < 0) continue;
+                for (int b = a; b < s->pt_first[l + 1]; b++) {
+                    const int f2 = s->free_of[pb->edge_pose[s->pt_edges[b]]];
+                    if (f2 >= 0) adj[(size_t)f1 * nf + f2] = 1;
+                }
+            }
+        s->sidx = (int32_t*)malloc(sizeof(int32_t) * ((size_t)nf * nf + 1));
+        int m = 0;
+        for (int f1 = 0; f1 < nf; f1++) for (int f2 = 0; f2 < nf; f2++)
+            s->sidx[(size_t)f1 * nf + f2] = (f2 >= f1 && adj[(size_t)f1 * nf + f2]) ? m++ : -1;
+        s->nsblk = m;
+        s->sblk = (double*)malloc(sizeof(double) * 36 * (size_t)(m + 1));
+        s->chol = orc_bchol_new(nf, adj);
+        free(adj);
+    }
     return s;
 }
 static void ba_free(ba_t* s)
 {
     free(s->free_of); free(s->R); free(s->active); free(s->err); free(s->Hpp); free(s->bp);
     free(s->Hll); free(s->bl); free(s->Hpl); free(s->Hs); free(s->bs); free(s->x); free(s->Dinv);
-    free(s->coeff); free(s->pt_first); free(s->pt_edges); free(s);
+    free(s->coeff); free(s->pt_first); free(s->pt_edges); free(s->sidx); free(s->sblk); orc_bchol_free(s->chol); free(s);
 }
 
 /* SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve per iteration */
@@ -529,7 +625,7 @@ int orc_ba_solve(orc_ba_problem* pb, const orc_ba_options* opt, orc_ba_result* r
 int orc_ba_reduced_system(const orc_ba_problem* pb, double huber_delta, double lambda,
                           double* Hschur, double* bschur, int32_t* free_index)
 {
-    ba_t* s = ba_new((orc_ba_problem*)pb);
+    ba_t* s = ba_new_mode((orc_ba_problem*)pb, 1);            /* dense by definition */
     s->huber_delta = huber_delta;
     compute_errors(s);
     build_system(s);
@@ -541,6 +637,24 @@ int orc_ba_reduced_system(const orc_ba_problem* pb, double huber_delta, double l
     const int P = s->nfree;
     ba_free(s);
     return P;
+}
+
+/* One linearisation at the current state solved with the selected solver (mode as orc_ba_set_solver): the keyframe
+ * increment xp [6 nfree] and the landmark increment xl [3 L]; returns nfree, or -1 when the factorisation fails.
+ * stats (optional): [0] non-zero blocks of the factor, [1] flops of one factorisation, [2] upper blocks of Hschur. */
+int orc_ba_solve_once(const orc_ba_problem* pb, double huber_delta, double lambda, int mode, double* xp, double* xl, double* stats)
+{
+    ba_t* s = ba_new_mode((orc_ba_problem*)pb, mode);
+    s->huber_delta = huber_delta;
+    compute_errors(s);
+    build_system(s);
+    const int ok = schur_solve(s, lambda);
+    const int n = 6 * s->nfree, P = s->nfree;
+    if (ok && xp) memcpy(xp, s->x, sizeof(double) * n);
+    if (ok && xl) memcpy(xl, s->x + n, sizeof(double) * 3 * (size_t)s->L);
+    if (stats) { stats[0] = s->chol ? (double)orc_bchol_nnz(s->chol) : 0; stats[1] = s->chol ? orc_bchol_flops(s->chol) : 0; stats[2] = s->nsblk; }
+    ba_free(s);
+    return ok ? P : -1;
 }
 
 /* ---------------------------------------------------------------- F2: pose-only optimisation

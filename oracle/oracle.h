@@ -134,6 +134,17 @@ int  orc_pose_optimize(double* pose7, const double* intr4, int n, const double* 
  * Hschur (6P x 6P, P = free poses, row-major, full symmetric) and bschur; returns P. */
 int  orc_ba_reduced_system(const orc_ba_problem*, double huber_delta, double lambda,
                            double* Hschur, double* bschur, int32_t* free_index);
+/* reduced solve selection (0 automatic: block-sparse Cholesky above 400 free keyframes, 1 dense Cholesky, 2 block-sparse) */
+void orc_ba_set_solver(int mode);
+int  orc_ba_solve_once(const orc_ba_problem*, double huber_delta, double lambda, int mode, double* xp, double* xl, double* stats);
+/* block-sparse Cholesky of the reduced camera system (bchol_oracle.c; linear_solver_eigen.h:106-136,165-222) */
+typedef struct orc_bchol orc_bchol;
+orc_bchol* orc_bchol_new(int nb, const uint8_t* adj);
+void orc_bchol_free(orc_bchol*);
+long orc_bchol_nnz(const orc_bchol*);
+double orc_bchol_flops(const orc_bchol*);
+int  orc_bchol_factor(orc_bchol*, const int32_t* idx, const double* blk);
+void orc_bchol_solve(const orc_bchol*, const double* b, double* x);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), 
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "bchol_oracle.c", "bow_oracle.c", "oracle.h")]
     if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return path
@@ -381,3 +381,20 @@ def essential_graph(sim3, fixed, edge_i, edge_j, meas, fix_scale=False, iteratio
     s = a(sim3, "f8").copy(); fx = a(fixed, np.uint8); ei = a(edge_i, "i4"); ej = a(edge_j, "i4"); ms = a(meas, "f8"); chi = np.zeros(2)
     done = lib().orc_essential_graph(len(s), _p(s), _p(fx), int(fix_scale), len(ei), _p(ei), _p(ej), _p(ms), int(iterations), _p(chi))
     return s, dict(iterations_done=done, chi2_initial=chi[0], chi2_final=chi[1])
+
+
+def ba_set_solver(mode: int):
+    """0 automatic (block-sparse Cholesky above 400 free keyframes), 1 dense Cholesky, 2 block-sparse Cholesky."""
+    lib().orc_ba_set_solver(int(mode))
+
+
+def ba_solve_once(g, huber_delta, lam, mode=0):
+    """One linearisation + reduced solve with the chosen solver: (xp [nfree,6], xl [L,3], stats) or None if not SPD."""
+    pb, keep = _ba_problem(g)
+    nfree = int((keep["fixed"] == 0).sum())
+    xp = np.zeros((nfree, 6)); xl = np.zeros((len(keep["points"]), 3)); st = np.zeros(3)
+    P = lib().orc_ba_solve_once(C.byref(pb), C.c_double(huber_delta), C.c_double(lam), int(mode), _p(xp), _p(xl), _p(st))
+    if P < 0:
+        return None
+    assert P == nfree
+    return xp, xl, dict(factor_blocks=int(st[0]), factor_flops=float(st[1]), schur_upper_blocks=int(st[2]))

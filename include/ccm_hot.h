@@ -52,7 +52,11 @@ void* ccm_stream(ccm_ctx*);
  * returns for each label the summed milliseconds and the number of launches since the last read,
  * and resets the sums.  Labels: see CCM_PROF_*. */
 enum { CCM_PROF_RESIZE = 0, CCM_PROF_FAST_SCORE, CCM_PROF_CELL_NMS, CCM_PROF_OCTREE, CCM_PROF_ORIENT_DESC,
-       CCM_PROF_HAMMING_BF, CCM_PROF_COUNT };
+       CCM_PROF_HAMMING_BF,
+       /* bundle adjustment: linearisation (k_ba_lin_landmark + k_ba_lin_pose), landmark inverse and Y = Hpl Dinv
+        * (k_sp_dinv + k_sp_edge_y), the Schur block GEMM (k_sp_schur_blocks), bschur, back-substitution */
+       CCM_PROF_BA_LINEARIZE, CCM_PROF_BA_DINV_Y, CCM_PROF_BA_SCHUR_BLOCKS, CCM_PROF_BA_BSCHUR, CCM_PROF_BA_BACKSUB,
+       CCM_PROF_COUNT };
 int ccm_profile_enable(ccm_ctx*, int on);
 int ccm_profile_read(ccm_ctx*, float ms[CCM_PROF_COUNT], int32_t launches[CCM_PROF_COUNT]);
 

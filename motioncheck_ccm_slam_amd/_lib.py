@@ -191,7 +191,8 @@ class Context:
             raise CcmError(rc, self.lib.ccm_last_error(self.handle).decode(errors="replace"))
         return rc
 
-    PROF_LABELS = ("k_pyr_resize", "k_fast_score", "k_cell_nms", "k_octree", "k_orient_desc", "k_hamming_bf")
+    PROF_LABELS = ("k_pyr_resize", "k_fast_score", "k_cell_nms", "k_octree", "k_orient_desc", "k_hamming_bf",
+                   "ba_linearize", "ba_dinv_y", "k_sp_schur_blocks", "k_sp_bschur", "k_ba_backsub")
 
     def profile(self, on: bool):
         self.check(self.lib.ccm_profile_enable(self.handle, int(on)))

@@ -271,7 +271,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     D.Hpp = S.Hpp.as<double>(); D.bp = S.bp.as<double>(); D.Hll = S.Hll.as<double>(); D.bl = S.bl.as<double>();
     D.Hpl = S.Hpl.as<double>(); D.Dinv = S.Dinv.as<double>();
     D.Hs = nullptr; D.bs = nullptr; D.x = S.x.as<double>();
-    double* scal = S.scal.as<double>();      // [0] chi2, [1] scale, [2] Hll max, ...
+    double* scal = S.scal.as<double>();      // [0] chi2, [1] scale, [2] stop flag (collective), [3] rank 0's verdict, [5] Hll max
     double* partial = S.partial.as<double>();
     int* info_dev = S.info_dev.as<int>();
 
@@ -386,17 +386,41 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     bool hb_in_use = false;                                // the side stream is still reading this trial's reduced system
     bool coarse_ready = false, coarse_pending = false;     // an inverse is in Aci / an inversion is running on the side stream
 
-    auto stop_requested = [&]() { return opt->stop_flag && *opt->stop_flag; };
+    // *pbStopFlag (sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149).  With several ranks the decision must be
+    // the same everywhere or a rank would leave the loop while the others wait in the next all-reduce: every rank's sample of
+    // its own flag rides on the chi2 all-reduce (a sum: non-zero = some rank saw it), and the loop tests that collective value.
+    bool stop_collective = false;
+    auto stop_requested = [&]() { return ranks > 1 ? stop_collective : (opt->stop_flag && *opt->stop_flag); };
+    auto sync_stop = [&]() -> int {                            // a dedicated exchange where no chi2 evaluation precedes the test
+        if (ranks <= 1) return CCM_OK;
+        S.pinned[13] = (opt->stop_flag && *opt->stop_flag) ? 1.0 : 0.0;
+        CCM_HIP(c, hipMemcpyAsync(scal + 2, S.pinned + 13, 8, hipMemcpyHostToDevice, st));
+        int r = comm_allreduce_f64(c, scal + 2, 1, false);
+        if (r) return r;
+        CCM_HIP(c, hipMemcpyAsync(S.pinned + 10, scal + 2, 8, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        stop_collective = S.pinned[10] > 0.0;
+        return CCM_OK;
+    };
     // chi2 (+ optionally scale) of the current state, summed over ranks
     auto eval_chi2 = [&](double hd, bool with_scale, double lambda, double* chi, double* scale) -> int {
         ba_launch_pose_rt(st, D);
         if (E > 0) ba_launch_errors(st, D, hd, partial, scal);
         else CCM_HIP(c, hipMemsetAsync(scal, 0, 8, st));
         if (with_scale) ba_launch_scale(st, D, lambda, rank == 0 ? 1 : 0, partial, scal + 1);
-        int r = comm_allreduce_f64(c, scal, with_scale ? 2 : 1, false);
-        if (r) return r;
-        CCM_HIP(c, hipMemcpyAsync(S.pinned + 8, scal, with_scale ? 16 : 8, hipMemcpyDeviceToHost, st));
-        CCM_HIP(c, hipStreamSynchronize(st));
+        if (ranks > 1) {
+            if (!with_scale) CCM_HIP(c, hipMemsetAsync(scal + 1, 0, 8, st));
+            S.pinned[13] = (opt->stop_flag && *opt->stop_flag) ? 1.0 : 0.0;
+            CCM_HIP(c, hipMemcpyAsync(scal + 2, S.pinned + 13, 8, hipMemcpyHostToDevice, st));
+            int r = comm_allreduce_f64(c, scal, 3, false);
+            if (r) return r;
+            CCM_HIP(c, hipMemcpyAsync(S.pinned + 8, scal, 24, hipMemcpyDeviceToHost, st));
+            CCM_HIP(c, hipStreamSynchronize(st));
+            stop_collective = S.pinned[10] > 0.0;
+        } else {
+            CCM_HIP(c, hipMemcpyAsync(S.pinned + 8, scal, with_scale ? 16 : 8, hipMemcpyDeviceToHost, st));
+            CCM_HIP(c, hipStreamSynchronize(st));
+        }
         *chi = S.pinned[8]; if (scale) *scale = S.pinned[9];
         return CCM_OK;
     };
@@ -414,6 +438,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         }
         double lambda = 0, ni = 2;
         int nBad = 0;
+        if ((rc = sync_stop())) return rc;
         for (int it = 0; it < iterations; it++) {
             if (stop_requested()) { res->stopped = 1; break; }                    // !terminate(), sparse_optimizer.cpp:376
             auto t0 = clk::now();
@@ -421,15 +446,15 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
             if ((rc = eval_chi2(huber, false, 0, &currentChi, nullptr))) return rc;
             const double iniChi = currentChi;
             if (first_eval) { res->chi2_initial = currentChi; first_eval = false; }
-            ba_launch_linearize(st, D, huber);                                      // buildSystem
+            { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_linearize(st, D, huber); }       // buildSystem
             if (it == 0) {                                                          // computeLambdaInit
-                ba_launch_diag(st, D, S.tmp_ll.as<double>(), S.pp_diag.as<double>(), scal + 2);
-                if (L == 0) CCM_HIP(c, hipMemsetAsync(scal + 2, 0, 8, st));
-                if ((rc = comm_allreduce_f64(c, scal + 2, 1, true))) return rc;
+                ba_launch_diag(st, D, S.tmp_ll.as<double>(), S.pp_diag.as<double>(), scal + 5);
+                if (L == 0) CCM_HIP(c, hipMemsetAsync(scal + 5, 0, 8, st));
+                if ((rc = comm_allreduce_f64(c, scal + 5, 1, true))) return rc;
                 if ((rc = comm_allreduce_f64(c, S.pp_diag.as<double>(), (size_t)n, false))) return rc;
                 std::vector<double> dg((size_t)n + 1);
                 CCM_HIP(c, hipMemcpyAsync(dg.data(), S.pp_diag.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-                CCM_HIP(c, hipMemcpyAsync(&dg[n], scal + 2, 8, hipMemcpyDeviceToHost, st));
+                CCM_HIP(c, hipMemcpyAsync(&dg[n], scal + 5, 8, hipMemcpyDeviceToHost, st));
                 CCM_HIP(c, hipStreamSynchronize(st));
                 double md = 0;
                 for (double v : dg) md = std::max(md, std::fabs(v));
@@ -446,10 +471,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 int ok2 = 1;
                 auto t2 = t1;
                 if (nfree > 0) {
-                    sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>());
-                    sp_launch_schur_blocks(st, D, S.Y.as<double>(), S.sp_val2.as<unsigned long long>(), S.seg_start.as<int>(), S.seg_end.as<int>(),
-                                           S.blk_row.as<int>(), S.blk_col.as<int>(), nb, Hb);
-                    sp_launch_bschur(st, D, S.db.as<double>(), D.bs);
+                    { ProfScope ps(c, CCM_PROF_BA_DINV_Y); sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>()); }
+                    { ProfScope ps(c, CCM_PROF_BA_SCHUR_BLOCKS);
+                      sp_launch_schur_blocks(st, D, S.Y.as<double>(), S.sp_val2.as<unsigned long long>(), S.seg_start.as<int>(), S.seg_end.as<int>(),
+                                             S.blk_row.as<int>(), S.blk_col.as<int>(), nb, Hb); }
+                    { ProfScope ps(c, CCM_PROF_BA_BSCHUR); sp_launch_bschur(st, D, S.db.as<double>(), D.bs); }
                     if ((rc = comm_allreduce_f64(c, Hb, 36 * (size_t)nb + (size_t)n, false))) return rc;
                     sp_launch_add_lambda(st, S.diag_id.as<int>(), nfree, lambda, Hb);
                     CCM_HIP(c, hipStreamSynchronize(st));
@@ -576,7 +602,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 res->trials++;
                 double tempChi = DBL_MAX, scale = 0;
                 if (ok2) {
-                    if (L > 0) ba_launch_backsub(st, D);
+                    if (L > 0) { ProfScope ps(c, CCM_PROF_BA_BACKSUB); ba_launch_backsub(st, D); }
                     ba_launch_update(st, D);
                     if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale))) return rc;
                 }

@@ -218,37 +218,37 @@ __global__ __launch_bounds__(256) void k_ba_deactivate(BaDev D, const uint8_t* _
 
 // ---- launchers
 static inline int nblk(long long n, int b) { return (int)((n + b - 1) / b); }
-void ba_launch_pose_rt(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_pose_rt, dim3(nblk(D.P, 256)), dim3(256), 0, s, D); }
+void ba_launch_pose_rt(hipStream_t s, const BaDev& D) { if (D.P > 0) hipLaunchKernelGGL(k_ba_pose_rt, dim3(nblk(D.P, 256)), dim3(256), 0, s, D); }
 int ba_errors_blocks(const BaDev& D) { return nblk(D.E, 256); }
 void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial, double* out)
 {
     const int nb = nblk(D.E, 256);
-    hipLaunchKernelGGL(k_ba_errors, dim3(nb), dim3(256), 0, s, D, hd, partial);
+    if (nb > 0) hipLaunchKernelGGL(k_ba_errors, dim3(nb), dim3(256), 0, s, D, hd, partial);
     hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, partial, nb, out, 0);
 }
 void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
 {
-    hipLaunchKernelGGL(k_ba_lin_landmark, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
     if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
 }
-void ba_launch_backsub(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_backsub, dim3(nblk(D.L, 256)), dim3(256), 0, s, D); }
+void ba_launch_backsub(hipStream_t s, const BaDev& D) { if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub, dim3(nblk(D.L, 256)), dim3(256), 0, s, D); }
 void ba_launch_update(hipStream_t s, const BaDev& D)
 {
     const int n = D.L > D.nfree ? D.L : D.nfree;
-    hipLaunchKernelGGL(k_ba_update, dim3(nblk(n, 256)), dim3(256), 0, s, D);
+    if (n > 0) hipLaunchKernelGGL(k_ba_update, dim3(nblk(n, 256)), dim3(256), 0, s, D);
 }
 int ba_scale_blocks(const BaDev& D) { return nblk(6LL * D.nfree + 3LL * D.L, 256); }
 void ba_launch_scale(hipStream_t s, const BaDev& D, double lambda, int add_pose_lambda, double* partial, double* out)
 {
     const int nb = ba_scale_blocks(D);
-    hipLaunchKernelGGL(k_ba_scale, dim3(nb), dim3(256), 0, s, D, lambda, add_pose_lambda, partial);
+    if (nb > 0) hipLaunchKernelGGL(k_ba_scale, dim3(nb), dim3(256), 0, s, D, lambda, add_pose_lambda, partial);
     hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, partial, nb, out, 0);
 }
 void ba_launch_diag(hipStream_t s, const BaDev& D, double* tmp_ll, double* pp_diag, double* out_ll_max)
 {
     const int n = D.L > D.nfree * 6 ? D.L : D.nfree * 6;
-    hipLaunchKernelGGL(k_ba_diag, dim3(nblk(n, 256)), dim3(256), 0, s, D, tmp_ll, pp_diag);
+    if (n > 0) hipLaunchKernelGGL(k_ba_diag, dim3(nblk(n, 256)), dim3(256), 0, s, D, tmp_ll, pp_diag);
     hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, tmp_ll, D.L, out_ll_max, 1);
 }
-void ba_launch_outliers(hipStream_t s, const BaDev& D, double th, uint8_t* flag) { hipLaunchKernelGGL(k_ba_outliers, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, th, flag); }
-void ba_launch_deactivate(hipStream_t s, const BaDev& D, const uint8_t* flag) { hipLaunchKernelGGL(k_ba_deactivate, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, flag); }
+void ba_launch_outliers(hipStream_t s, const BaDev& D, double th, uint8_t* flag) { if (D.E > 0) hipLaunchKernelGGL(k_ba_outliers, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, th, flag); }
+void ba_launch_deactivate(hipStream_t s, const BaDev& D, const uint8_t* flag) { if (D.E > 0) hipLaunchKernelGGL(k_ba_deactivate, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, flag); }

@@ -21,6 +21,18 @@ TH_HUBER_2D_LOCAL = float(np.sqrt(5.991))    # src/Optimizer.cpp:468
 CHI2_MONO = 5.991                            # src/Optimizer.cpp:556, :582
 
 
+def _stop_flag_view(stop_flag):
+    """pbStopFlag is a `bool*` another thread writes while the solve runs (src/Optimizer.cpp:160, :531): the library must
+    poll the caller's own byte, so only a writable one-byte array (uint8 / bool) is accepted -- a Python bool, a list or
+    an array of another dtype would be copied and could never stop the solve."""
+    if stop_flag is None:
+        return None
+    if not isinstance(stop_flag, np.ndarray) or stop_flag.dtype.itemsize != 1 or stop_flag.size < 1 \
+            or not stop_flag.flags.c_contiguous or not stop_flag.flags.writeable:
+        raise TypeError("pbStopFlag must be a writable numpy array of uint8 or bool (the library polls its first byte in place)")
+    return stop_flag.view(np.uint8)
+
+
 def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None, pcg_tol=0.0):
     lib = _lib.load()
     keep = dict(
@@ -33,7 +45,7 @@ def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None, pcg_tol
                    len(keep["points"]), p(keep["points"]), len(keep["edge_pose"]),
                    p(keep["edge_pose"]), p(keep["edge_point"]), p(keep["obs"]), p(keep["info"]))
     outl = np.zeros(max(len(keep["edge_pose"]), 1), np.uint8)
-    flag = None if stop_flag is None else np.ascontiguousarray(stop_flag, np.uint8)
+    flag = _stop_flag_view(stop_flag)
     opt = BaOptions(int(iterations), float(huber), int(iterations2), CHI2_MONO, p(flag), float(pcg_tol))
     res = BaResult()
     res.edge_outlier = p(outl)

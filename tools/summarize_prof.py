@@ -51,8 +51,9 @@ if len(sys.argv) >= 5:
                   "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024), "launches_sampled": fe[k][1],
                   "note": "FETCH_SIZE x2 (gfx950 correction for streamed reads; uncalibrated for byte-wide loads) + WRITE_SIZE"}
     if len(sys.argv) >= 6:
-        # vector-ALU issue utilisation: a wave64 VALU instruction holds its SIMD for >= 4 cycles and the chip has
-        # 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        # vector-ALU issue occupancy: measured cost of a wave64 instruction on a saturated SIMD (tools/valu_calib.hip,
+        # profiles/r02_valu_issue_calibration.txt): 2.3 cycles for plain ALU ops, 4.2 for packed / 3-operand / SDWA / dot / perm
+        # ones; the chip has 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs.  Bounds = all-cheap .. all-expensive.
         names = ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"]
         sq = {nm: counter(sys.argv[5], nm) for nm in names}
         for k in sorted(set(sq["SQ_INSTS_VALU"])):
@@ -62,7 +63,7 @@ if len(sys.argv) >= 5:
             e = out.setdefault(k, {})
             e.update({"valu_insts_per_launch": int(m["SQ_INSTS_VALU"]), "waves_per_launch": int(m["SQ_WAVES"]),
                       "busy_cycles_per_launch": int(cyc),
-                      "valu_issue_frac": round(m["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 4) if cyc else None,
+                      "valu_issue_frac_bounds": [round(m["SQ_INSTS_VALU"] * 2.3 / (1024.0 * cyc), 4), round(m["SQ_INSTS_VALU"] * 4.2 / (1024.0 * cyc), 4)] if cyc else None,
                       "wait_any_frac_of_wave_cycles": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 4) if m["SQ_WAVE_CYCLES"] else None})
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    for k, v in out.items(): print(k, v.get("hbm_bytes_per_launch"), v.get("valu_issue_frac"))
+    for k, v in out.items(): print(k, v.get("hbm_bytes_per_launch"), v.get("valu_issue_frac_bounds"))

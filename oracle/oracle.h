@@ -40,6 +40,7 @@ float orc_fast_atan2(float y, float x);
 int  orc_round_half_even(double v);
 float orc_ic_angle(const uint8_t* img, int stride, int cx, int cy, const int32_t* umax);
 void orc_orb_descriptor(const uint8_t* blurred, int stride, int cx, int cy, float angle_deg, uint8_t* desc32);
+void orc_set_sincos_libm(int on);   /* 1: libm cosf/sinf as ORBextractor.cpp:105 (measurement only), 0: include/ccm_sincos.h */
 int  orc_distribute_octree(const int32_t* xy, const int32_t* score, int n, int minX, int maxX,
                            int minY, int maxY, int N, int32_t* out_idx);
 /* Full operator().  level_out (optional) receives pointers-free copies of the pyramid:

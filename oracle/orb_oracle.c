@@ -295,12 +295,19 @@ float orc_ic_angle(const uint8_t* img, int stride, int cx, int cy, const int32_t
 /* ------------------------------------------------------------------ A8: computeOrbDescriptor
  * ORBextractor.cpp:100-316.  Byte i uses pattern points 16i..16i+15; bit k of
  * byte i is I(point 16i+2k) < I(point 16i+2k+1). */
+/* 0 (default): the shared fixed-order sine/cosine of include/ccm_sincos.h, which the HIP kernel evaluates too.
+ * 1: this machine's libm cosf/sinf, i.e. literally what ORBextractor.cpp:105 calls.  The switch exists to MEASURE how far
+ * the shared function departs from the reference's libm (tests/test_sincos_cpu.py); parity tests use 0. */
+static int g_sincos_libm = 0;
+void orc_set_sincos_libm(int on) { g_sincos_libm = on; }
+
 void orc_orb_descriptor(const uint8_t* img, int stride, int cx, int cy, float angle_deg, uint8_t* desc)
 {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);   /* :98 */
     const float angle = angle_deg * factorPI;                          /* :104 */
     float a, b;
-    ccm_sincosf(angle, &b, &a);                                        /* :105 a=cos, b=sin */
+    if (g_sincos_libm) { a = cosf(angle); b = sinf(angle); }           /* :105 exactly as written */
+    else ccm_sincosf(angle, &b, &a);                                   /* :105 a=cos, b=sin */
     const uint8_t* c = img + (size_t)cy * stride + cx;
     for (int i = 0; i < 32; i++) {
         int val = 0;

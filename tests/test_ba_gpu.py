@@ -99,6 +99,21 @@ def test_gba_config5_matches_the_oracle_at_full_size(ctx, pcg_tol):
     assert np.isclose(r["lambda_final"], float(z["lambda_final"]), rtol=1e-6)
 
 
+def test_gba_config5_optimize20_matches_the_oracle(ctx):
+    """The reference's own call on config 5: optimize(20) (cslam/conf/config.yaml:129).  g2o's stop criterion (three iterations
+    in a row gaining < 0.1 % of chi2, optimization_algorithm_levenberg.cpp:154-161) ends it after 9 iterations in the oracle;
+    the HIP path must stop at the same iteration with the same state (lambda has fallen to 0.04 by then, the hardest reduced
+    systems of the run for the PCG)."""
+    z = np.load(os.path.join(G, "gba_config5.npz"))
+    g = synth.gba_graph()
+    r = Optimizer.MapFusionGBA(g, 20, ctx=ctx)
+    assert [r["iterations_done"], r["trials"]] == list(z["iterations20"]) and r["pcg_fallbacks"] == 0
+    d = pose_delta(r["poses"], z["poses20"]).max()
+    dp = np.abs(r["points"][::int(z["point_stride"])] - z["points20_sub"]).max()
+    assert d <= TOL and dp <= 1e-5, (d, dp)
+    assert np.isclose(r["chi2_final"], z["chi2_20"][1], rtol=1e-9) and np.isclose(r["lambda_final"], float(z["lambda20"]), rtol=1e-6)
+
+
 def test_full_gba_properties(ctx):
     """BASELINE config 5 at full size (2000 KF / 200k points), beyond the 5 iterations of the golden comparison above:
     size-independent properties: chi2 decreases monotonically over accepted iterations, the fixed
@@ -112,6 +127,37 @@ def test_full_gba_properties(ctx):
     assert (again["poses"] == r3["poses"]).all() and (again["points"] == r3["points"]).all()      # fixed summation orders: bit-reproducible
     e0 = pose_delta(g["poses"], g["gt_poses"]); e1 = pose_delta(r6["poses"], g["gt_poses"])
     assert np.median(e1) < 0.25 * np.median(e0)
+
+
+def test_stop_flag_raised_mid_solve(ctx):
+    """*pbStopFlag set by another thread WHILE config 5 is being optimised (sparse_optimizer.cpp:376 tests it before every
+    iteration, optimization_algorithm_levenberg.cpp:149 inside the trial loop): the solve ends early with `stopped`, and its
+    result is the result of a run asked for exactly the iterations it completed."""
+    import threading, time
+    g = synth.gba_graph()
+    Optimizer.MapFusionGBA(g, 1, ctx=ctx)                                   # allocations and graph capture out of the way
+    flag = np.zeros(1, np.uint8)
+    N = 8                                                                   # (g2o's own stop criterion ends this graph after 9)
+    t_full = time.perf_counter(); full = Optimizer.MapFusionGBA(g, N, ctx=ctx); t_full = time.perf_counter() - t_full
+    assert not full["stopped"] and full["iterations_done"] == N
+
+    def raiser():
+        time.sleep(0.45 * t_full)
+        flag[0] = 1
+    th = threading.Thread(target=raiser); th.start()
+    r = Optimizer.MapFusionGBA(g, N, pbStopFlag=flag, ctx=ctx)
+    th.join()
+    assert r["stopped"] and 0 < r["iterations_done"] < N, (r["stopped"], r["iterations_done"])
+    k = r["iterations_done"]
+    ref = Optimizer.MapFusionGBA(g, k, ctx=ctx)
+    if r["trials"] == ref["trials"]:                                       # the flag did not cut a retry loop short
+        assert (r["poses"] == ref["poses"]).all() and (r["points"] == ref["points"]).all() and r["chi2_final"] == ref["chi2_final"]
+    else:
+        assert r["chi2_final"] <= r["chi2_initial"]
+    with pytest.raises(TypeError):
+        Optimizer.MapFusionGBA(g, 1, pbStopFlag=True, ctx=ctx)              # a Python bool can never be raised by another thread
+    with pytest.raises(TypeError):
+        Optimizer.MapFusionGBA(g, 1, pbStopFlag=np.zeros(1, np.int32), ctx=ctx)
 
 
 def test_larger_map_widens_the_coarse_aggregates(ctx):
@@ -211,6 +257,40 @@ print("ok")
     assert (a["poses"] == b["poses"]).all() and (a["points"] == b["points"]).all(), \
         "the ranks disagree on the result: max |d poses| %.3e, max |d points| %.3e" % (np.abs(a["poses"] - b["poses"]).max(), np.abs(a["points"] - b["points"]).max())
     assert int(a["pairs"]) > 0 and int(b["pairs"]) > 0 and int(a["pairs"]) != int(b["pairs"])      # each rank enumerated its own share
+
+
+def test_sharded_gba_stop_flag_on_one_rank_only(tmp_path):
+    """Two ranks on one GPU (shared-memory transport); only rank 1's stop flag is set.  The decision is collective (the flag
+    rides on the chi2 all-reduce), so BOTH ranks stop before the first iteration instead of rank 0 waiting for ever in the
+    next all-reduce."""
+    import subprocess, sys, uuid
+    code = r'''
+import sys
+import numpy as np
+from motioncheck_ccm_slam_amd import _lib, synth, dist
+from motioncheck_ccm_slam_amd.optimizer import Optimizer
+rank, name = int(sys.argv[1]), sys.argv[2]
+ctx = _lib.Context(0)
+dist.init_comm_shm(ctx, name, rank, 2)
+g = synth.gba_graph(n_kf=120, n_points=8000, n_agents=3, seed=120)
+flag = np.full(1, 1 if rank == 1 else 0, np.uint8)
+r = Optimizer.MapFusionGBA(g, 4, pbStopFlag=flag, ctx=ctx)
+assert r["stopped"] and r["iterations_done"] == 0 and (r["poses"] == g["poses"]).all(), (rank, r["stopped"], r["iterations_done"])
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "/ccm_test_" + uuid.uuid4().hex[:12]
+    env = dict(os.environ, PYTHONPATH=root)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(rk), name], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for rk in (0, 1)]
+    try:
+        outs = [p.communicate(timeout=300) + (p.returncode,) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for o, e, rc in outs:
+        assert rc == 0 and o.strip().endswith("ok"), o[-1500:] + e[-1500:]
 
 
 def test_rccl_calls_with_one_rank_communicator():

@@ -70,3 +70,17 @@ def test_optimizers_with_nothing_to_optimise(ctx):
     with pytest.raises(Exception):
         Optimizer.OptimizeEssentialGraph(s3, np.zeros(4, np.uint8), [0], [9], ident, ctx=ctx)
     assert len(Optimizer.CorrectMapPoints(E("f8", 3), E("i4"), s3, s3, ctx=ctx)) == 0
+
+
+def test_bundle_adjustment_with_no_landmarks_or_no_edges(ctx):
+    """ccm_ba_solve accepts n_points == 0 and n_edges == 0 (a pose-only map, or a rank whose landmark shard is empty): every
+    launch whose grid derives from the landmark / edge count is skipped, the call returns CCM_OK and nothing moves."""
+    g = synth.local_ba_graph(n_free=4, n_fixed=2, n_points=200, seed=9)
+    none = dict(g, points=np.zeros((0, 3)), edge_pose=np.zeros(0, "i4"), edge_point=np.zeros(0, "i4"), obs=np.zeros((0, 2)), info=np.zeros(0))
+    r = Optimizer.BundleAdjustmentClient(none, 3, ctx=ctx)
+    assert (r["poses"] == g["poses"]).all() and len(r["points"]) == 0
+    r = Optimizer.LocalBundleAdjustmentClient(none, ctx=ctx)
+    assert (r["poses"] == g["poses"]).all()
+    no_edges = dict(g, edge_pose=np.zeros(0, "i4"), edge_point=np.zeros(0, "i4"), obs=np.zeros((0, 2)), info=np.zeros(0))
+    r = Optimizer.BundleAdjustmentClient(no_edges, 3, ctx=ctx)
+    assert (r["poses"] == g["poses"]).all() and (r["points"] == g["points"]).all()

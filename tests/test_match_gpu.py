@@ -74,7 +74,8 @@ def test_ragged_counts_below_2048_trains(ctx, oracle):
 
 
 def test_many_pairs_property(ctx, oracle):
-    """A slice of config 3 (10k pairs in the bench): 512 pairs, symmetric checks on all, oracle on a sample."""
+    """A 512-pair slice of config 3 through the host-buffer entry point (ORBmatcher.BruteForce): symmetric checks on all,
+    oracle on a sample.  The full 10,000 pairs are the next test."""
     m = ORBmatcher(0.7, ctx=ctx)
     q, t = synth.descriptor_pairs(100, 512)
     bi, bd, sd = m.BruteForce(q, t)
@@ -86,6 +87,44 @@ def test_many_pairs_property(ctx, oracle):
     for p in (0, 100, 511):
         rbi, rbd, rsd = oracle.hamming_match(q[p], t[p])
         assert (bi[p] == rbi).all() and (sd[p] == rsd).all()
+
+
+def test_config3_all_10000_pairs(ctx, oracle):
+    """BASELINE config 3 at its stated size: 10,000 pairs of 1000 x 1000 descriptors (seeds 0xDE5C0000 + p), generated on the
+    device by the torch twin of synth.descriptor_pairs (bit-identical, tests/test_synth_cpu.py), matched in ONE launch of the
+    device-resident entry point as bench.py's match_10k leg does.  Size-independent properties on every pair -- index range,
+    best <= second, the reported best distance IS the distance to the reported index, no sampled train row is closer, the
+    planted inlier is found -- and bit equality with the oracle on 20 pairs spread over the whole range."""
+    import ctypes as C
+    import torch
+    from motioncheck_ccm_slam_amd import _lib
+    lib = _lib.load()
+    NP = 10000
+    qa, tb = synth.descriptor_pairs_torch(0, NP, device="cuda")
+    bi = torch.empty((NP, 1000), dtype=torch.int32, device="cuda"); bd = torch.empty_like(bi); sd = torch.empty_like(bi)
+    torch.cuda.synchronize()
+    ctx.check(lib.ccm_hamming_match_dev(ctx.handle, C.c_void_p(qa.data_ptr()), 1000, C.c_size_t(1000), C.c_void_p(tb.data_ptr()), 1000,
+                                        C.c_size_t(1000), NP, None, None, C.c_void_p(bi.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(sd.data_ptr())))
+    ctx.sync()
+    assert bool(((bi >= 0) & (bi < 1000)).all()) and bool((bd <= sd).all()) and bool((bd >= 0).all()) and bool((sd <= 256).all())
+    lut = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.int16, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    n_inlier_hits = 0
+    for p0 in range(0, NP, 500):
+        q = qa[p0:p0 + 500]; t = tb[p0:p0 + 500]; idx = bi[p0:p0 + 500].long()
+        sel = torch.gather(t, 1, idx[:, :, None].expand(-1, -1, 32))
+        true = lut[(q ^ sel).long()].sum(-1, dtype=torch.int32)
+        assert bool((true == bd[p0:p0 + 500]).all()), p0
+        rnd = torch.randint(0, 1000, (500, 1000), device="cuda", generator=g)
+        other = torch.gather(t, 1, rnd[:, :, None].expand(-1, -1, 32))
+        d_other = lut[(q ^ other).long()].sum(-1, dtype=torch.int32)
+        assert bool((d_other >= bd[p0:p0 + 500]).all()), p0                       # nothing sampled beats the reported best
+        assert bool(((d_other >= sd[p0:p0 + 500]) | (rnd == idx)).all()), p0      # and nothing but the best beats the second
+        n_inlier_hits += int((bd[p0:p0 + 500] < 40).sum())
+    assert n_inlier_hits > 0.6 * NP * 1000                                        # 70 % of the rows carry a planted match at ~15 bits
+    for p in list(range(0, NP, 625)) + [1, 4999, 5000, 9999]:
+        rbi, rbd, rsd = oracle.hamming_match(qa[p].cpu().numpy(), tb[p].cpu().numpy())
+        assert (bi[p].cpu().numpy() == rbi).all() and (bd[p].cpu().numpy() == rbd).all() and (sd[p].cpu().numpy() == rsd).all(), p
 
 
 @pytest.mark.parametrize("kfkf", [False, True])

@@ -90,8 +90,15 @@ def main():
     dt = time.time() - t0
     print("oracle %d LM iterations: %.1f s (%.3f it/s)" % (ITERS, dt, r["iterations_done"] / dt),
           {k: v for k, v in r.items() if not hasattr(v, "shape")})
+    # the reference's own call: optimize(20) (cslam/conf/config.yaml:129); g2o's stop criterion (three iterations in a row gaining
+    # less than 0.1 % of chi2, optimization_algorithm_levenberg.cpp:154-161) ends it earlier on this graph
+    t0 = time.time()
+    r20 = O.ba_solve(g, 20, HUBER)
+    print("oracle optimize(20): %.1f s" % (time.time() - t0), {k: v for k, v in r20.items() if not hasattr(v, "shape")})
     out = os.path.join(ROOT, "tests", "golden", "gba_config5.npz")
-    np.savez_compressed(out, poses=r["poses"], points_sub=r["points"][::POINT_STRIDE], point_stride=np.array(POINT_STRIDE),
+    np.savez_compressed(out, poses20=r20["poses"], points20_sub=r20["points"][::POINT_STRIDE], chi2_20=np.array([r20["chi2_initial"], r20["chi2_final"]]),
+                        iterations20=np.array([r20["iterations_done"], r20["trials"]]), lambda20=np.array(r20["lambda_final"]),
+                        poses=r["poses"], points_sub=r["points"][::POINT_STRIDE], point_stride=np.array(POINT_STRIDE),
                         points_sum=r["points"].sum(0), chi2=np.array([r["chi2_initial"], r["chi2_final"]]),
                         iterations=np.array([r["iterations_done"], r["trials"]]), lambda_final=np.array(r["lambda_final"]),
                         lin_check=np.array([lam, rel]), factor_blocks=np.array(st["factor_blocks"]),

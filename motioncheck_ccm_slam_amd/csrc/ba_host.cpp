@@ -161,6 +161,7 @@ int ccm_ba_landmark_cuts(const int32_t* edge_point, int n_edges, int n_points, i
 
 int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_ba_result* res)
 {
+    RoctxRange roctx_("ccm_ba_solve");
     if (!c || !pb || !opt) return CCM_E_ARG;
     if (pb->n_poses <= 0 || pb->n_points < 0 || pb->n_edges < 0 || !pb->poses || !pb->intr ||
         (pb->n_points > 0 && !pb->points) || (pb->n_edges > 0 && (!pb->edge_pose || !pb->edge_point || !pb->obs || !pb->info)))
@@ -442,6 +443,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         for (int it = 0; it < iterations; it++) {
             if (stop_requested()) { res->stopped = 1; break; }                    // !terminate(), sparse_optimizer.cpp:376
             auto t0 = clk::now();
+            RoctxRange lin_("ba:linearize");
             double currentChi = 0;
             if ((rc = eval_chi2(huber, false, 0, &currentChi, nullptr))) return rc;
             const double iniChi = currentChi;
@@ -461,11 +463,13 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 lambda = 1e-5 * md; ni = 2; nBad = 0;
             }
             CCM_HIP(c, hipStreamSynchronize(st));
+            lin_.end();
             res->t_linearize += secs(t0, clk::now());
             double rho = 0;
             int qmax = 0;
             do {
                 auto t1 = clk::now();
+                RoctxRange trial_("ba:trial (schur + solve + update)");
                 CCM_HIP(c, hipMemcpyAsync(S.save_poses.p, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));   // push
                 if (L) CCM_HIP(c, hipMemcpyAsync(S.save_points.p, D.points, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
                 int ok2 = 1;

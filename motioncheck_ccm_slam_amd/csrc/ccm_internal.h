@@ -1,6 +1,7 @@
 // ccm_internal.h -- shared between the host-side translation units of libccm_hot.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <roctracer/roctx.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -85,6 +86,17 @@ struct ProfScope {
         L.used++;
     }
     ~ProfScope() { if (stop) (void)hipEventRecord(stop, c->stream); }
+};
+
+// Named range in rocprofv3 --marker-trace / roctracer timelines (the reference's only instrumentation is
+// g2o's G2OBatchStatistics, block_solver.hpp:441-453, mirrored by the timers of ccm_ba_result; these ranges show where a
+// call's host time goes next to the kernels).  A push/pop pair costs ~50 ns when no tool is attached.
+struct RoctxRange {
+    bool open = true;
+    explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+    void end() { if (open) { roctxRangePop(); open = false; } }       // close before the scope ends (early returns still balance)
+    ~RoctxRange() { end(); }
+    RoctxRange(const RoctxRange&) = delete; RoctxRange& operator=(const RoctxRange&) = delete;
 };
 
 void orb_state_free(OrbState*);

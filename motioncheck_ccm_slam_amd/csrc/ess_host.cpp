@@ -35,6 +35,7 @@ void ess_state_free(EssState* s)
 
 extern "C" int ccm_optimize_essential_graph(ccm_ctx* c, ccm_essential_graph* g)
 {
+    RoctxRange roctx_("ccm_optimize_essential_graph");
     if (!c || !g) return CCM_E_ARG;
     g->iterations_done = 0; g->chi2_initial = 0; g->chi2_final = 0;
     const int nv = g->n_vertices, ne = g->n_edges;

@@ -68,6 +68,7 @@ int ccm_hamming_match_dev(ccm_ctx* c, const uint8_t* q_dev, int nq, size_t q_pai
                           size_t t_pair_stride, int n_pairs, const int32_t* nq_n_dev, const int32_t* nt_n_dev,
                           int32_t* best_idx_dev, int32_t* best_dist_dev, int32_t* second_dist_dev)
 {
+    RoctxRange roctx_("ccm_hamming_match_dev");
     if (!c) return CCM_E_ARG;
     if (n_pairs == 0 || nq == 0) return CCM_OK;
     if (n_pairs < 0 || nq < 0 || nt < 0 || nt > 65535 || !q_dev || (!t_dev && nt > 0) || !best_idx_dev || !best_dist_dev || !second_dist_dev)
@@ -98,6 +99,7 @@ int ccm_hamming_match_dev(ccm_ctx* c, const uint8_t* q_dev, int nq, size_t q_pai
 int ccm_hamming_match(ccm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int n_pairs, const int32_t* nq_n,
                       const int32_t* nt_n, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
 {
+    RoctxRange roctx_("ccm_hamming_match");
     if (!c) return CCM_E_ARG;
     if (n_pairs == 0 || nq == 0) return CCM_OK;
     if (n_pairs < 0 || nq < 0 || nt < 0 || !q || (!t && nt > 0) || !best_idx || !best_dist || !second_dist)
@@ -199,6 +201,7 @@ int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, co
                   const float* angle1, int n1, const uint8_t* desc2, const int32_t* node2, const uint8_t* valid2,
                   const float* angle2, int n2, int32_t* match12)
 {
+    RoctxRange roctx_("ccm_match_bow");
     if (!c || !o) return CCM_E_ARG;
     if (n1 < 0 || n2 < 0 || (n1 > 0 && (!desc1 || !node1 || !valid1 || !match12)) || (n2 > 0 && (!desc2 || !node2)) ||
         (o->check_ori && n1 > 0 && n2 > 0 && (!angle1 || !angle2)))

@@ -374,6 +374,7 @@ int ccm_orb_level_sizes(const ccm_orb_params* p, int w, int h, int32_t* level_w,
 int ccm_orb_extract_dev(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img_dev, int w, int h, int stride,
                         size_t image_stride, int n_images, int max_per_image)
 {
+    RoctxRange roctx_("ccm_orb_extract_dev");
     if (!c || !p) return CCM_E_ARG;
     if (n_images == 0 || w == 0 || h == 0) return CCM_OK;         // empty image: silent return (:1219-1220)
     if (!img_dev || w < 0 || h < 0 || n_images < 0 || stride < w || (n_images > 1 && image_stride < (size_t)stride * h))
@@ -386,6 +387,7 @@ int ccm_orb_extract_dev(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img_
 
 int ccm_orb_fetch(ccm_ctx* c, ccm_keypoint* kps, uint8_t* desc, int32_t* counts)
 {
+    RoctxRange roctx_("ccm_orb_fetch");
     if (!c || !c->orb || !c->orb->have_result) return c ? ccm_fail(c, CCM_E_STATE, "no extraction to fetch") : CCM_E_ARG;
     OrbState& S = *c->orb;
     int rc = orb_check_status(c);
@@ -401,6 +403,7 @@ int ccm_orb_extract(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img, int
                     size_t image_stride, int n_images, ccm_keypoint* kps, uint8_t* desc, int32_t* counts,
                     int max_per_image)
 {
+    RoctxRange roctx_("ccm_orb_extract");
     if (!c || !p) return CCM_E_ARG;
     if (n_images == 0 || w == 0 || h == 0) return CCM_OK;
     if (!img || w < 0 || h < 0 || n_images < 0 || stride < w) return ccm_fail(c, CCM_E_ARG, "bad image arguments");

@@ -27,6 +27,7 @@ void pose_state_free(PoseState* s)
 
 extern "C" int ccm_pose_optimize(ccm_ctx* c, ccm_pose_problem* pb)
 {
+    RoctxRange roctx_("ccm_pose_optimize");
     if (!c || !pb) return CCM_E_ARG;
     if (pb->n_frames == 0) return CCM_OK;
     if (pb->n_frames < 0 || !pb->poses || !pb->intr || !pb->first || !pb->n_inliers) return ccm_fail(c, CCM_E_ARG, "bad pose problem");

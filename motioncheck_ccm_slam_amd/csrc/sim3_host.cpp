@@ -21,6 +21,7 @@ void sim3_state_free(Sim3State* s)
 
 extern "C" int ccm_optimize_sim3(ccm_ctx* c, ccm_sim3_problem* pb)
 {
+    RoctxRange roctx_("ccm_optimize_sim3");
     if (!c || !pb) return CCM_E_ARG;
     if (pb->n_problems == 0) return CCM_OK;
     if (pb->n_problems < 0 || !pb->sim3 || !pb->fix_scale || !pb->K1 || !pb->K2 || !pb->first || !pb->th2 || !pb->n_inliers)

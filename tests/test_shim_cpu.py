@@ -1,0 +1,120 @@
+"""shim/*.cpp (the drop-in bodies of cslam::ORBextractor / ORBmatcher / Optimizer) against include/ccm_hot.h.
+
+The shim needs the reference's headers, OpenCV and Boost, none of which exist in this image, so it cannot be compiled here
+(shim/CMakeLists.txt builds it where they do).  What CAN rot silently is its use of the C ABI; this test parses the
+prototypes and the struct definitions of ccm_hot.h and checks every ccm_* call and every ccm_* aggregate initialiser in the
+shim sources: the symbol exists, the argument count matches, the field count matches.  The same check runs over the code
+blocks of INTEGRATION.md."""
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _strip_comments(t):
+    t = re.sub(r"/\*.*?\*/", " ", t, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", t)
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{<" and not (ch == "<" and depth == 0 and False):
+            depth += ch != "<"
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _balanced(t, i, open_ch, close_ch):
+    depth, j = 0, i
+    while j < len(t):
+        if t[j] == open_ch: depth += 1
+        elif t[j] == close_ch:
+            depth -= 1
+            if depth == 0:
+                return t[i + 1:j], j
+        j += 1
+    raise AssertionError("unbalanced")
+
+
+def _header():
+    h = _strip_comments(open(os.path.join(ROOT, "include", "ccm_hot.h")).read())
+    protos = {}
+    for m in re.finditer(r"\b(ccm_\w+)\s*\(", h):
+        name = m.group(1)
+        args, end = _balanced(h, m.end() - 1, "(", ")")
+        if h[end + 1:end + 3].strip().startswith(";"):
+            a = [x for x in _split_top(args) if x.strip() and x.strip() != "void"]
+            protos[name] = len(a)
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s*\{", h):
+        body, end = _balanced(h, m.end() - 1, "{", "}")
+        nm = re.match(r"\s*(ccm_\w+)\s*;", h[end + 1:])
+        if nm:
+            fields = [f for f in body.split(";") if f.strip()]
+            structs[nm.group(1)] = sum(len(_split_top(f)) for f in fields)
+    return protos, structs
+
+
+def _check(text, protos, structs, where):
+    t = _strip_comments(text)
+    calls = 0
+    for m in re.finditer(r"\b(ccm_\w+)\s*\(", t):
+        name = m.group(1)
+        if name in structs or name == "ccm_shim":
+            continue
+        assert name in protos, "%s: %s is not declared in ccm_hot.h" % (where, name)
+        args, _ = _balanced(t, m.end() - 1, "(", ")")
+        n = len([x for x in _split_top(args) if x.strip()])
+        assert n == protos[name], "%s: %s called with %d arguments, prototype has %d" % (where, name, n, protos[name])
+        calls += 1
+    for m in re.finditer(r"\b(ccm_\w+)\s+\w+\s*\{", t):
+        name = m.group(1)
+        if name not in structs:
+            continue
+        body, _ = _balanced(t, m.end() - 1, "{", "}")
+        n = len([x for x in _split_top(body) if x.strip()])
+        # fewer initialisers than fields is legal (the rest are the struct's outputs, zero-initialised); more is an error
+        assert n <= structs[name], "%s: %s initialised with %d fields, the struct has %d" % (where, name, n, structs[name])
+    return calls
+
+
+def test_shim_sources_use_the_abi_as_declared():
+    protos, structs = _header()
+    assert len(protos) >= 49 and "ccm_ba_solve" in protos and structs["ccm_ba_problem"] == 11
+    files = sorted(glob.glob(os.path.join(ROOT, "shim", "*.cpp")) + glob.glob(os.path.join(ROOT, "shim", "*.h")))
+    assert len(files) >= 4
+    total = sum(_check(open(f).read(), protos, structs, os.path.basename(f)) for f in files)
+    assert total >= 10
+    used = set(re.findall(r"\b(ccm_\w+)\s*\(", "".join(_strip_comments(open(f).read()) for f in files)))
+    for needed in ("ccm_orb_tables", "ccm_orb_extract", "ccm_descriptor_distance", "ccm_match_bow", "ccm_search_by_projection",
+                   "ccm_ba_solve", "ccm_pose_optimize", "ccm_pose_from_mat4f", "ccm_pose_to_mat4f", "ccm_create"):
+        assert needed in used, needed
+
+
+def test_integration_md_snippets_use_the_abi_as_declared():
+    protos, structs = _header()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", md, flags=re.S)
+    assert len(blocks) >= 6
+    for i, b in enumerate(blocks):
+        b = re.sub(r"\.\.\.", " ", b)
+        _check(b, protos, structs, "INTEGRATION.md block %d" % i)
+
+
+def test_every_reference_signature_the_shim_defines_exists_in_the_reference_headers_text():
+    """The member functions the shim defines are spelled as in the reference's headers (checked against names only: the
+    headers themselves are not in this repository)."""
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "shim", "*.cpp")))
+    for name in ("ORBextractor::operator()", "ORBextractor::ORBextractor", "ORBmatcher::DescriptorDistance", "ORBmatcher::SearchByBoW",
+                 "ORBmatcher::SearchByProjection", "Optimizer::MapFusionGBA", "Optimizer::BundleAdjustmentClient",
+                 "Optimizer::GlobalBundleAdjustemntClient", "Optimizer::PoseOptimizationClient"):
+        assert name in src, name

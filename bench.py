@@ -298,7 +298,8 @@ def main():
             from motioncheck_ccm_slam_amd.optimizer import Optimizer
             if world > 1:
                 if os.environ.get("CCM_BENCH_COMM") == "shm":
-                    D.init_comm_shm(ctx, "/ccm_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world)
+                    from tests.support import shm_transport                 # rehearsal only: test scaffolding, not the product
+                    shm_transport.attach(ctx, "/ccm_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world)
                 else:
                     D.init_comm(ctx, rank, world)
             g = synth.gba_graph()

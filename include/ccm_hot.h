@@ -428,10 +428,19 @@ int ccm_ba_landmark_cuts(const int32_t* edge_point, int n_edges, int n_points, i
 #define CCM_COMM_ID_BYTES 128
 int ccm_comm_unique_id(uint8_t id[CCM_COMM_ID_BYTES]);
 int ccm_comm_init(ccm_ctx*, const uint8_t id[CCM_COMM_ID_BYTES], int n_ranks, int rank);
-/* Rehearsal transport for machines with ONE GPU: the ranks are processes of this host that exchange through the POSIX
- * shared-memory segment `name` (rank 0 creates it; capacity_bytes per rank must hold the largest all-reduce: 36 doubles
- * per reduced-camera block + 6 per keyframe).  Same data path as ccm_comm_init except for the all-reduce itself. */
-int ccm_comm_init_shm(ccm_ctx*, const char* name, int n_ranks, int rank, size_t capacity_bytes);
+/* Bring-your-own transport: a host that already has a collective layer (MPI, a test harness) attaches it instead of
+ * RCCL.  The callbacks receive DEVICE pointers and the context's HIP stream; they must leave the reduced values in
+ * place and return 0, or non-zero on failure (reported as CCM_E_COMM).  `destroy` runs when the context drops the
+ * communicator.  The sharded solve is the same code path as with ccm_comm_init except for the all-reduce itself.
+ * (tests/support/shm_transport.cpp, a shared-memory all-reduce between processes sharing ONE GPU, is such a transport:
+ * it lets the sharded global BA be rehearsed end to end on a one-GPU box; it is not part of this library.) */
+typedef struct {
+    void* user;
+    int  (*allreduce_f64)(void* user, double* dev, size_t n, int max_op, void* hip_stream);
+    int  (*allreduce_u8_max)(void* user, uint8_t* dev, size_t n, void* hip_stream);
+    void (*destroy)(void* user);
+} ccm_comm_transport;
+int ccm_comm_attach(ccm_ctx*, const ccm_comm_transport*, int n_ranks, int rank);
 int ccm_comm_destroy(ccm_ctx*);
 
 /* SE3Quat / Converter helpers (src/Converter.cc:40-56, 86-93): float32 4x4 row-major

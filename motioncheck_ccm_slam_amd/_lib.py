@@ -31,7 +31,7 @@ SYMBOLS = [
     "ccm_window_candidates", "ccm_search_by_projection", "ccm_search_by_projection_frame", "ccm_search_for_initialization", "ccm_fuse_select", "ccm_search_by_sim3", "ccm_search_by_projection_sim3",
     "ccm_search_for_triangulation", "ccm_voc_create", "ccm_voc_destroy", "ccm_voc_words", "ccm_voc_transform", "ccm_voc_transform_dev",
     "ccm_bow_vector", "ccm_bow_score_l1", "ccm_distinctive_descriptors", "ccm_optimize_sim3", "ccm_optimize_essential_graph", "ccm_correct_map_points",
-    "ccm_ba_solve", "ccm_ba_landmark_cuts", "ccm_pose_optimize", "ccm_comm_unique_id", "ccm_comm_init", "ccm_comm_init_shm", "ccm_comm_destroy",
+    "ccm_ba_solve", "ccm_ba_landmark_cuts", "ccm_pose_optimize", "ccm_comm_unique_id", "ccm_comm_init", "ccm_comm_attach", "ccm_comm_destroy",
     "ccm_pose_from_mat4f", "ccm_pose_to_mat4f",
 ]
 
@@ -154,7 +154,7 @@ def load():
     lib.ccm_distinctive_descriptors.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     lib.ccm_ba_solve.argtypes = [vp, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaResult)]
     lib.ccm_ba_landmark_cuts.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
-    lib.ccm_comm_init_shm.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_size_t]
+    lib.ccm_comm_attach.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.ccm_pose_optimize.argtypes = [vp, C.POINTER(PoseProblem)]
     lib.ccm_optimize_sim3.argtypes = [vp, C.POINTER(Sim3Problem)]
     lib.ccm_optimize_essential_graph.argtypes = [vp, C.POINTER(EssentialGraph)]

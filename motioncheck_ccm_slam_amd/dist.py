@@ -61,24 +61,21 @@ def init_comm(ctx, rank: int, world: int):
     import torch.distributed as dist
     from . import _lib
     lib = _lib.load()
-    ident = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
+    # the id travels with a status byte: if rank 0 cannot make one, EVERY rank raises instead of waiting in the broadcast
+    msg = np.zeros(_lib.COMM_ID_BYTES + 1, np.uint8)
     if rank == 0:
+        ident = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
         rc = lib.ccm_comm_unique_id(_lib.ptr(ident))
-        if rc:
-            raise _lib.CcmError(rc, "ccm_comm_unique_id")
-    t = torch.from_numpy(ident.copy())
+        msg[:_lib.COMM_ID_BYTES] = ident
+        msg[-1] = 1 if rc else 0
+    t = torch.from_numpy(msg.copy())
     if world > 1:
         if dist.get_backend() == "nccl":
             t = t.cuda()
         dist.broadcast(t, src=0)
         t = t.cpu()
-    ident = t.numpy().astype(np.uint8)
+    msg = t.numpy().astype(np.uint8)
+    if msg[-1]:
+        raise _lib.CcmError(-6, "ccm_comm_unique_id failed on rank 0")
+    ident = np.ascontiguousarray(msg[:_lib.COMM_ID_BYTES])
     ctx.check(lib.ccm_comm_init(ctx.handle, _lib.ptr(ident), world, rank))
-
-
-def init_comm_shm(ctx, name: str, rank: int, world: int, capacity_bytes: int = 64 << 20):
-    """Rehearsal transport (one GPU, several processes): all-reduce through a POSIX shared-memory segment instead of
-    RCCL.  Everything else of the sharded solve is the production path."""
-    from . import _lib
-    lib = _lib.load()
-    ctx.check(lib.ccm_comm_init_shm(ctx.handle, name.encode(), int(world), int(rank), int(capacity_bytes)))

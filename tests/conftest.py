@@ -22,7 +22,16 @@ def _have_gpu():
 
 @pytest.fixture(scope="session")
 def ctx():
-    """A ccm context on GPU 0.  GPU tests fail (not skip) when the library is missing."""
+    """A ccm context on GPU 0.  GPU tests fail (not skip) when the library is missing.
+    torch is initialised FIRST where a GPU is present: a few tests use torch tensors as device buffers (as bench.py does), and
+    torch's bundled HIP runtime refuses to come up ("No HIP GPUs are available") once libccm_hot.so has initialised the
+    system one in the same process; in the other order both share torch's copy."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from motioncheck_ccm_slam_amd import _lib
     return _lib.default_context(0)
 

@@ -221,9 +221,10 @@ import sys
 import numpy as np
 from motioncheck_ccm_slam_amd import _lib, synth, dist
 from motioncheck_ccm_slam_amd.optimizer import Optimizer, pose_delta
+from tests.support import shm_transport
 rank, name, out = int(sys.argv[1]), sys.argv[2], sys.argv[3]
 ctx = _lib.Context(0)
-dist.init_comm_shm(ctx, name, rank, 2)
+shm_transport.attach(ctx, name, rank, 2)
 g = synth.gba_graph(n_kf=240, n_points=20000, n_agents=3, seed=240)
 r = Optimizer.MapFusionGBA(g, 4, ctx=ctx)
 if rank == 0:
@@ -269,9 +270,10 @@ import sys
 import numpy as np
 from motioncheck_ccm_slam_amd import _lib, synth, dist
 from motioncheck_ccm_slam_amd.optimizer import Optimizer
+from tests.support import shm_transport
 rank, name = int(sys.argv[1]), sys.argv[2]
 ctx = _lib.Context(0)
-dist.init_comm_shm(ctx, name, rank, 2)
+shm_transport.attach(ctx, name, rank, 2)
 g = synth.gba_graph(n_kf=120, n_points=8000, n_agents=3, seed=120)
 flag = np.full(1, 1 if rank == 1 else 0, np.uint8)
 r = Optimizer.MapFusionGBA(g, 4, pbStopFlag=flag, ctx=ctx)

@@ -398,7 +398,9 @@ int ccm_optimize_sim3(ccm_ctx*, ccm_sim3_problem*);
  * (src/Optimizer.cpp:1064-1331, :1333-1574): one VertexSim3Expmap per keyframe (sim3 = Scw or the corrected Sim3,
  * :1094-1108; fixed = pLoopKF, :1110), one EdgeSim3 per loop / spanning-tree / covisibility edge built by the caller
  * exactly as :1123-1250 with edge_i = vertex 0, edge_j = vertex 1, measurement = Sji; identity information, numeric
- * Jacobians, Levenberg with lambda 1e-16, `iterations` = 20.  sim3 comes back as the CorrectedSiw of :1262. */
+ * Jacobians, Levenberg with lambda 1e-16, `iterations` = 20.  sim3 comes back as the CorrectedSiw of :1262.
+ * Solved like :1072-1074 (BlockSolver_7_3 + sparse Cholesky): block-sparse normal equations, fill-reducing ordering once per call,
+ * numeric factorisation per LM trial on the device; no dense matrix. */
 typedef struct {
     int32_t        n_vertices;
     double*        sim3;          /* [n_vertices][8] in/out: qx,qy,qz,qw, tx,ty,tz, s */
@@ -411,6 +413,10 @@ typedef struct {
     int32_t        iterations;
     int32_t        iterations_done;   /* out */
     double         chi2_initial, chi2_final;   /* out */
+    /* out, the block-sparse solve: 7x7 blocks of the Cholesky factor (diagonal + lower, fill included), rounds of independent
+     * columns (= launches per factorisation), device bytes of system + factor */
+    int32_t        factor_blocks, factor_rounds;
+    int64_t        solver_bytes;
 } ccm_essential_graph;
 int ccm_optimize_essential_graph(ccm_ctx*, ccm_essential_graph*);
 /* Map point correction that follows it (:1300-1330): points[i] <- correctedSwr.map(Srw.map(points[i])) with r =

@@ -79,7 +79,8 @@ class Sim3Problem(C.Structure):
 class EssentialGraph(C.Structure):
     _fields_ = [("n_vertices", C.c_int), ("sim3", C.c_void_p), ("fixed", C.c_void_p), ("fix_scale", C.c_int), ("n_edges", C.c_int),
                 ("edge_i", C.c_void_p), ("edge_j", C.c_void_p), ("measurement", C.c_void_p), ("iterations", C.c_int),
-                ("iterations_done", C.c_int), ("chi2_initial", C.c_double), ("chi2_final", C.c_double)]
+                ("iterations_done", C.c_int), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("factor_blocks", C.c_int), ("factor_rounds", C.c_int), ("solver_bytes", C.c_int64)]
 
 
 class BaOptions(C.Structure):

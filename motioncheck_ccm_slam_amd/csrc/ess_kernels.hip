@@ -4,8 +4,7 @@
 //   k_ess_errors     thread = (edge, variant): variant 0 = the error, 1..14 = vertex 0 perturbed by +-delta along d,
 //                    15..28 = vertex 1 likewise; error = log(Sji * Siw * Sjw^-1)   (types_seven_dof_expmap.h:119-127)
 //   k_ess_blocks     thread = edge: Jacobians from the 29 errors, J^T J blocks and J^T e
-//   k_ess_assemble   thread = free vertex: diagonal block and gradient = sums over its incident edges in edge order;
-//                    off-diagonal blocks are added per edge (one edge per vertex pair: a single, exact addition)
+//   k_essp_*         block-sparse normal equations on the graph's pattern and their Cholesky factorisation / solves
 //   k_ess_update     VertexSim3Expmap::oplusImpl per free vertex
 //   k_ess_chi2       sum |e|^2 in a fixed order
 #include <hip/hip_runtime.h>
@@ -69,35 +68,166 @@ __global__ __launch_bounds__(64) void k_ess_blocks(int ne, const double* __restr
     }
 }
 
-// inc_ptr/inc_list: per vertex its incident (edge << 1 | role) entries in edge order; fidx[v] = free index or -1
-__global__ __launch_bounds__(64) void k_ess_assemble(int nv, const int* __restrict__ fidx, const int* __restrict__ inc_ptr, const int* __restrict__ inc_list,
-                                                     const double* __restrict__ blocks, const double* __restrict__ grad, int N,
-                                                     double* __restrict__ H, double* __restrict__ b)
+// ------------------------------------------------------------------------------------------------
+// Block-sparse normal equations and their Cholesky factorisation (7x7 blocks on the essential graph's pattern), the
+// counterpart of g2o's BlockSolver_7_3 + sparse LinearSolverEigen (src/Optimizer.cpp:1072-1074).  The host orders the free
+// keyframes by rounds of independent minimum-degree eliminations (ess_host.cpp) and hands over, for every block of the
+// factor, the list of (L_ik, L_jk) products it needs; every sum below runs over such a list in its stored order, so the
+// result is bit-reproducible.  Storage: D[c][49] diagonal blocks, Lb[slot][49] strictly-lower blocks, row-major, permuted
+// order.  Columns of one round are independent: one workgroup per column, one launch per round.
+//
+// b: per free vertex (original free index) the gradient sum, in edge order
+__global__ __launch_bounds__(64) void k_essp_grad(int nv, const int* __restrict__ fidx, const int* __restrict__ inc_ptr, const int* __restrict__ inc_list,
+                                                  const double* __restrict__ grad, double* __restrict__ b)
 {
     const int v = blockIdx.x, t = threadIdx.x;
     const int f = fidx[v];
-    if (f < 0) return;
-    if (t < 49) {
-        double a = 0;
-        for (int q = inc_ptr[v]; q < inc_ptr[v + 1]; q++) { const int en = inc_list[q]; a += blocks[147LL * (en >> 1) + 49 * (en & 1) + t]; }
-        H[(long long)(7 * f + t / 7) * N + 7 * f + t % 7] = a;
-    } else if (t < 56) {
-        double g = 0;
-        for (int q = inc_ptr[v]; q < inc_ptr[v + 1]; q++) { const int en = inc_list[q]; g += grad[14LL * (en >> 1) + 7 * (en & 1) + (t - 49)]; }
-        b[7 * f + (t - 49)] = g;
+    if (f < 0 || t >= 7) return;
+    double g = 0;
+    for (int q = inc_ptr[v]; q < inc_ptr[v + 1]; q++) { const int en = inc_list[q]; g += grad[14LL * (en >> 1) + 7 * (en & 1) + t]; }
+    b[7 * f + t] = g;
+}
+
+// A: target t < ncol is the diagonal block of column t, target ncol + s the lower block in slot s.  alist entry = edge * 4 + code,
+// code 0: Ji^T Ji, 1: Jj^T Jj, 2: Ji^T Jj, 3: (Ji^T Jj)^T.  Targets the pattern adds by fill-in have empty lists (zero blocks).
+__global__ __launch_bounds__(64) void k_essp_assemble(int ntargets, int ncol, const int* __restrict__ aptr, const int* __restrict__ alist,
+                                                      const double* __restrict__ blocks, double* __restrict__ D, double* __restrict__ Lb)
+{
+    const int t = blockIdx.x, e = threadIdx.x;
+    if (t >= ntargets || e >= 49) return;
+    const int p = e / 7, q = e - 7 * p;
+    double a = 0;
+    for (int k = aptr[t]; k < aptr[t + 1]; k++) {
+        const int en = alist[k], code = en & 3;
+        const double* B = blocks + 147LL * (en >> 2);
+        a += code == 3 ? B[98 + q * 7 + p] : B[49 * code + e];
+    }
+    if (t < ncol) D[49LL * t + e] = a; else Lb[49LL * (t - ncol) + e] = a;
+}
+
+// One round of the left-looking factorisation.  Column j (= cols[blockIdx.x]):
+//   D_j  <- chol( A_jj + lambda I - sum_k L_jk L_jk^T )
+//   L_ij <- ( A_ij - sum_k L_ik L_jk^T ) D_j^-T            for every block (i, j) of the column
+// tptr / tpa / tpb: per target (numbered as in k_essp_assemble) the slots of the two factors of each product, ascending k.
+__global__ __launch_bounds__(256) void k_essp_factor(const int* __restrict__ cols, const int* __restrict__ colptr, int ncol, const int* __restrict__ tptr,
+                                                     const int* __restrict__ tpa, const int* __restrict__ tpb, double lambda,
+                                                     double* __restrict__ D, double* __restrict__ Lb, int* __restrict__ bad)
+{
+    __shared__ double Ljj[49];
+    const int j = cols[blockIdx.x], tid = threadIdx.x;
+    if (tid < 49) {
+        const int r = tid / 7, c2 = tid - 7 * r;
+        double a = D[49LL * j + tid] + (r == c2 ? lambda : 0.0);
+        for (int k = tptr[j]; k < tptr[j + 1]; k++) {
+            const double* A = Lb + 49LL * tpa[k] + 7 * r; const double* B = Lb + 49LL * tpb[k] + 7 * c2;
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++) v += A[q] * B[q];
+            a -= v;
+        }
+        Ljj[tid] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {                                       // 7x7 Cholesky, lower, in place
+        for (int c2 = 0; c2 < 7; c2++) {
+            double d = Ljj[c2 * 7 + c2];
+            for (int k = 0; k < c2; k++) d -= Ljj[c2 * 7 + k] * Ljj[c2 * 7 + k];
+            if (!(d > 0.0)) { atomicOr(bad, 1); d = 1.0; }
+            d = sqrt(d); Ljj[c2 * 7 + c2] = d;
+            const double id = 1.0 / d;
+            for (int r = c2 + 1; r < 7; r++) {
+                double v = Ljj[r * 7 + c2];
+                for (int k = 0; k < c2; k++) v -= Ljj[r * 7 + k] * Ljj[c2 * 7 + k];
+                Ljj[r * 7 + c2] = v * id;
+            }
+            for (int r = 0; r < c2; r++) Ljj[r * 7 + c2] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < 49) D[49LL * j + tid] = Ljj[tid];
+    // thread = (block of the column, row of the block): the row's 7 sums, then its forward substitution against Ljj
+    const int c0 = colptr[j], nb = colptr[j + 1] - c0;
+    for (int w = tid; w < nb * 7; w += 256) {
+        const int s = c0 + w / 7, r = w % 7;
+        double row[7];
+#pragma unroll
+        for (int q = 0; q < 7; q++) row[q] = Lb[49LL * s + 7 * r + q];
+        const int t = ncol + s;
+        for (int k = tptr[t]; k < tptr[t + 1]; k++) {
+            const double* A = Lb + 49LL * tpa[k] + 7 * r; const double* B = Lb + 49LL * tpb[k];
+            double av[7];
+#pragma unroll
+            for (int q = 0; q < 7; q++) av[q] = A[q];
+#pragma unroll
+            for (int c2 = 0; c2 < 7; c2++) {
+                double v = 0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) v += av[q] * B[7 * c2 + q];
+                row[c2] -= v;
+            }
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 7; c2++) {
+            double v = row[c2];
+            for (int q = 0; q < c2; q++) v -= row[q] * Ljj[c2 * 7 + q];
+            row[c2] = v / Ljj[c2 * 7 + c2];
+        }
+#pragma unroll
+        for (int q = 0; q < 7; q++) Lb[49LL * s + 7 * r + q] = row[q];
     }
 }
-__global__ __launch_bounds__(64) void k_ess_offdiag(int ne, const int* __restrict__ ei, const int* __restrict__ ej, const int* __restrict__ fidx,
-                                                    const double* __restrict__ blocks, int N, double* __restrict__ H)
+
+// forward round: y_j = D_j^-1 ( b_perm(j) - sum_{k < j} L_jk y_k ); rptr / rslot / rcol: row j's blocks, ascending k
+__global__ __launch_bounds__(64) void k_essp_forward(const int* __restrict__ cols, const int* __restrict__ perm, const int* __restrict__ rptr,
+                                                     const int* __restrict__ rslot, const int* __restrict__ rcol, const double* __restrict__ D,
+                                                     const double* __restrict__ Lb, const double* __restrict__ b, double* __restrict__ y)
 {
-    const int k = blockIdx.x, t = threadIdx.x;
-    if (k >= ne || t >= 49) return;
-    const int fi = fidx[ei[k]], fj = fidx[ej[k]];
-    if (fi < 0 || fj < 0 || fi == fj) return;
-    const int p = t / 7, q = t % 7;
-    const double c = blocks[147LL * k + 98 + t];                      // (Ji^T Jj)[p][q]
-    unsafeAtomicAdd(&H[(long long)(7 * fi + p) * N + 7 * fj + q], c);
-    unsafeAtomicAdd(&H[(long long)(7 * fj + q) * N + 7 * fi + p], c);
+    __shared__ double acc[7];
+    const int j = cols[blockIdx.x], t = threadIdx.x;
+    if (t < 7) {
+        double a = b[7LL * perm[j] + t];
+        for (int k = rptr[j]; k < rptr[j + 1]; k++) {
+            const double* L = Lb + 49LL * rslot[k] + 7 * t; const double* yk = y + 7LL * rcol[k];
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++) v += L[q] * yk[q];
+            a -= v;
+        }
+        acc[t] = a;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const double* Ljj = D + 49LL * j;
+        double o[7];
+        for (int r = 0; r < 7; r++) { double v = acc[r]; for (int q = 0; q < r; q++) v -= Ljj[r * 7 + q] * o[q]; o[r] = v / Ljj[r * 7 + r]; }
+        for (int r = 0; r < 7; r++) y[7LL * j + r] = o[r];
+    }
+}
+// backward round: x_j = D_j^-T ( y_j - sum_{i > j} L_ij^T x_i ); the column's blocks in row order; x leaves in ORIGINAL free order too
+__global__ __launch_bounds__(64) void k_essp_backward(const int* __restrict__ cols, const int* __restrict__ perm, const int* __restrict__ colptr,
+                                                      const int* __restrict__ rowidx, const double* __restrict__ D, const double* __restrict__ Lb,
+                                                      const double* __restrict__ y, double* __restrict__ xp, double* __restrict__ x)
+{
+    __shared__ double acc[7];
+    const int j = cols[blockIdx.x], t = threadIdx.x;
+    if (t < 7) {
+        double a = y[7LL * j + t];
+        for (int s = colptr[j]; s < colptr[j + 1]; s++) {
+            const double* L = Lb + 49LL * s; const double* xi = xp + 7LL * rowidx[s];
+            double v = 0;
+#pragma unroll
+            for (int r = 0; r < 7; r++) v += L[7 * r + t] * xi[r];
+            a -= v;
+        }
+        acc[t] = a;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const double* Ljj = D + 49LL * j;
+        double o[7];
+        for (int r = 6; r >= 0; r--) { double v = acc[r]; for (int q = r + 1; q < 7; q++) v -= Ljj[q * 7 + r] * o[q]; o[r] = v / Ljj[r * 7 + r]; }
+        for (int r = 0; r < 7; r++) { xp[7LL * j + r] = o[r]; x[7LL * perm[j] + r] = o[r]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ess_update(int nv, const int* __restrict__ fidx, const double* __restrict__ x, int fix_scale, double* __restrict__ sim3)
@@ -132,25 +262,29 @@ __global__ void k_ess_chi2_fin(int nb, const double* __restrict__ part, double* 
     for (int i = 0; i < nb; i++) s += part[i];
     *out = s;
 }
-__global__ __launch_bounds__(256) void k_ess_add_lambda(int N, double lambda, double* __restrict__ H)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < N) H[(long long)j * N + j] += lambda;
-}
-
 void ess_launch_errors(hipStream_t s, int ne, const int* ei, const int* ej, const double* meas, const double* sim3, const uint8_t* fixed, int fix_scale,
                        int variants, double* err)
 {
     const long long n = (long long)ne * variants;
     if (n > 0) hipLaunchKernelGGL(k_ess_errors, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ne, ei, ej, meas, sim3, fixed, fix_scale, variants, err);
 }
-void ess_launch_system(hipStream_t s, int ne, int nv, const int* ei, const int* ej, const int* fidx, const int* inc_ptr, const int* inc_list,
-                       const double* err, double* blocks, double* grad, int N, double* H, double* b)
+void ess_launch_blocks(hipStream_t s, int ne, int nv, const int* fidx, const int* inc_ptr, const int* inc_list, const double* err, double* blocks,
+                       double* grad, double* b)
 {
     hipLaunchKernelGGL(k_ess_blocks, dim3((ne + 63) / 64), dim3(64), 0, s, ne, err, blocks, grad);
-    hipLaunchKernelGGL(k_ess_assemble, dim3(nv), dim3(64), 0, s, nv, fidx, inc_ptr, inc_list, blocks, grad, N, H, b);
-    hipLaunchKernelGGL(k_ess_offdiag, dim3(ne), dim3(64), 0, s, ne, ei, ej, fidx, blocks, N, H);
+    hipLaunchKernelGGL(k_essp_grad, dim3(nv), dim3(64), 0, s, nv, fidx, inc_ptr, inc_list, grad, b);
 }
+void essp_launch_assemble(hipStream_t s, int ntargets, int ncol, const int* aptr, const int* alist, const double* blocks, double* D, double* Lb)
+{ if (ntargets > 0) hipLaunchKernelGGL(k_essp_assemble, dim3(ntargets), dim3(64), 0, s, ntargets, ncol, aptr, alist, blocks, D, Lb); }
+void essp_launch_factor_round(hipStream_t s, const int* cols, int n, const int* colptr, int ncol, const int* tptr, const int* tpa, const int* tpb,
+                              double lambda, double* D, double* Lb, int* bad)
+{ if (n > 0) hipLaunchKernelGGL(k_essp_factor, dim3(n), dim3(256), 0, s, cols, colptr, ncol, tptr, tpa, tpb, lambda, D, Lb, bad); }
+void essp_launch_forward_round(hipStream_t s, const int* cols, int n, const int* perm, const int* rptr, const int* rslot, const int* rcol,
+                               const double* D, const double* Lb, const double* b, double* y)
+{ if (n > 0) hipLaunchKernelGGL(k_essp_forward, dim3(n), dim3(64), 0, s, cols, perm, rptr, rslot, rcol, D, Lb, b, y); }
+void essp_launch_backward_round(hipStream_t s, const int* cols, int n, const int* perm, const int* colptr, const int* rowidx, const double* D,
+                                const double* Lb, const double* y, double* xp, double* x)
+{ if (n > 0) hipLaunchKernelGGL(k_essp_backward, dim3(n), dim3(64), 0, s, cols, perm, colptr, rowidx, D, Lb, y, xp, x); }
 void ess_launch_update(hipStream_t s, int nv, const int* fidx, const double* x, int fix_scale, double* sim3)
 { hipLaunchKernelGGL(k_ess_update, dim3((nv + 255) / 256), dim3(256), 0, s, nv, fidx, x, fix_scale, sim3); }
 void ess_launch_chi2(hipStream_t s, int ne, const double* err, int stride, double* part, double* out)
@@ -159,8 +293,6 @@ void ess_launch_chi2(hipStream_t s, int ne, const double* err, int stride, doubl
     hipLaunchKernelGGL(k_ess_chi2, dim3(nb), dim3(256), 0, s, ne, err, stride, part);
     hipLaunchKernelGGL(k_ess_chi2_fin, dim3(1), dim3(64), 0, s, nb, part, out);
 }
-void ess_launch_add_lambda(hipStream_t s, int N, double lambda, double* H)
-{ hipLaunchKernelGGL(k_ess_add_lambda, dim3((N + 255) / 256), dim3(256), 0, s, N, lambda, H); }
 
 // Map point correction after the pose graph (src/Optimizer.cpp:1300-1330): P' = correctedSwr.map(Srw.map(P))
 __global__ __launch_bounds__(256) void k_ess_correct_points(int np, const int* __restrict__ ref, const double* __restrict__ s_old, const double* __restrict__ s_new,

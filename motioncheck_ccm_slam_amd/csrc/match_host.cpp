@@ -269,8 +269,11 @@ int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, co
 
 // ------------------------------------------------------------------------------------------------
 // F1: windowed matching.  The GPU enumerates, for every query, the features inside its
-// search window with their Hamming distances (k_window_candidates); the sequential acceptance of each
-// matcher stays on the host in the reference's visiting order.
+// search window with their Hamming distances (k_window_candidates).  The acceptance runs on the device too for the matchers
+// a server batches over many map points: Fuse / SearchBySim3 (k_window_select: no coupling between queries), and
+// SearchByProjection(Frame, map points) / SearchByProjection(KF, Scw) (k_window_greedy: the reference's order-dependent
+// occupancy bookkeeping resolved by claim rounds, bit-identical to the sequential loop).  The frame-to-frame and the
+// initialisation matcher (rotation histograms over all accepted matches) keep their acceptance loops on the host.
 struct WinGrid {
     int n, cols, rows; float min_x, min_y, inv_w, inv_h;
     const float* kx; const float* ky; const int* oct; const uint8_t* desc; const int* cell_first; const int* cell_items;
@@ -278,11 +281,26 @@ struct WinGrid {
 void match_launch_window(hipStream_t, const WinGrid&, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
                          const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn);
 
-struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn; };
+void match_launch_window_select(hipStream_t, const WinGrid&, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
+                                const int* maxl, const uint8_t* qdesc, const float* inv_sigma2, int accept_th, int* best_idx, int* best_dist);
+struct GreedyArgs {
+    int nq, n, cap; const int* ci; const int* cd; const int* cn; const uint8_t* active; const int* qlevel; const int* oct; const uint8_t* qflag;
+    uint8_t* flag; float nnratio; int* out; int* status;
+};
+size_t match_window_greedy_lds(int n, int nq);
+int match_launch_window_greedy(hipStream_t, int mode, const GreedyArgs&);
 
-static int window_candidates(ccm_ctx* c, const ccm_frame_grid* f, int nq, const float* qx, const float* qy, const float* qr,
-                             const int32_t* minl, const int32_t* maxl, const uint8_t* qdesc, int cap,
-                             std::vector<int32_t>& ci, std::vector<int32_t>& cd, std::vector<int32_t>& cn)
+struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn, sel_i, sel_d, is2, act, qlvl, qflag, flag, out, status; };
+// LDS the single-workgroup acceptance kernel may ask for (claim + flag per feature, one byte per query); larger problems take the
+// host loops below
+static const size_t kGreedyLdsMax = 150 * 1024;
+
+// mode 0: candidate lists to the host (ci / cd / cn); 1: lists stay in HBM for k_window_greedy; 2: no lists, k_window_select
+// leaves one (index, distance) per query in W.sel_i / W.sel_d
+static int window_run(ccm_ctx* c, const ccm_frame_grid* f, int nq, const float* qx, const float* qy, const float* qr,
+                      const int32_t* minl, const int32_t* maxl, const uint8_t* qdesc, int cap, int mode,
+                      std::vector<int32_t>& ci, std::vector<int32_t>& cd, std::vector<int32_t>& cn,
+                      const float* inv_sigma2 = nullptr, int n_levels = 0, int accept_th = 0)
 {
     if (!c->match) c->match = new MatchState();
     if (!c->match->win) c->match->win = new WindowBufs();
@@ -310,12 +328,21 @@ static int window_candidates(ccm_ctx* c, const ccm_frame_grid* f, int nq, const 
         (rc = up(W.qr, qr, (size_t)nq * 4)) || (rc = up(W.minl, minl, (size_t)nq * 4)) || (rc = up(W.maxl, maxl, (size_t)nq * 4)) ||
         (rc = up(W.qdesc, qdesc, (size_t)nq * 32)))
         return rc;
-    CCM_RESERVE(c, W.ci, (size_t)nq * cap * 4); CCM_RESERVE(c, W.cd, (size_t)nq * cap * 4); CCM_RESERVE(c, W.cn, (size_t)nq * 4);
     WinGrid G{ n, f->grid_cols, f->grid_rows, f->min_x, f->min_y, f->inv_w, f->inv_h, W.kx.as<float>(), W.ky.as<float>(), W.oct.as<int>(),
                W.desc.as<uint8_t>(), W.cfirst.as<int>(), W.citems.as<int>() };
+    if (mode == 2) {
+        CCM_RESERVE(c, W.sel_i, (size_t)nq * 4); CCM_RESERVE(c, W.sel_d, (size_t)nq * 4);
+        if (inv_sigma2 && (rc = up(W.is2, inv_sigma2, (size_t)n_levels * 4))) return rc;
+        match_launch_window_select(st, G, nq, W.qx.as<float>(), W.qy.as<float>(), W.qr.as<float>(), W.minl.as<int>(), W.maxl.as<int>(),
+                                   W.qdesc.as<uint8_t>(), inv_sigma2 ? W.is2.as<float>() : nullptr, accept_th, W.sel_i.as<int>(), W.sel_d.as<int>());
+        CCM_HIP(c, hipGetLastError());
+        return CCM_OK;
+    }
+    CCM_RESERVE(c, W.ci, (size_t)nq * cap * 4); CCM_RESERVE(c, W.cd, (size_t)nq * cap * 4); CCM_RESERVE(c, W.cn, (size_t)nq * 4);
     match_launch_window(st, G, nq, W.qx.as<float>(), W.qy.as<float>(), W.qr.as<float>(), W.minl.as<int>(), W.maxl.as<int>(),
                         W.qdesc.as<uint8_t>(), cap, W.ci.as<int>(), W.cd.as<int>(), W.cn.as<int>());
     CCM_HIP(c, hipGetLastError());
+    if (mode == 1) return CCM_OK;
     ci.resize((size_t)nq * cap); cd.resize((size_t)nq * cap); cn.resize(nq);
     CCM_HIP(c, hipMemcpyAsync(ci.data(), W.ci.p, ci.size() * 4, hipMemcpyDeviceToHost, st));
     CCM_HIP(c, hipMemcpyAsync(cd.data(), W.cd.p, cd.size() * 4, hipMemcpyDeviceToHost, st));
@@ -324,10 +351,57 @@ static int window_candidates(ccm_ctx* c, const ccm_frame_grid* f, int nq, const 
     return CCM_OK;
 }
 
+static int window_candidates(ccm_ctx* c, const ccm_frame_grid* f, int nq, const float* qx, const float* qy, const float* qr,
+                             const int32_t* minl, const int32_t* maxl, const uint8_t* qdesc, int cap,
+                             std::vector<int32_t>& ci, std::vector<int32_t>& cd, std::vector<int32_t>& cn)
+{
+    return window_run(c, f, nq, qx, qy, qr, minl, maxl, qdesc, cap, 0, ci, cd, cn);
+}
+
+// The order-dependent acceptance on the device (k_window_greedy): candidate lists stay in HBM, in: per-query active / level / flag and
+// the per-feature flags; out: `out` (n_out ints, pre-set to -1), the updated flags, the number of matches.  Returns the match count,
+// or < 0 on error.  Lists longer than `cap` make the kernel report the needed length and the call repeats once.
+static int window_greedy(ccm_ctx* c, const ccm_frame_grid* f, int nq, const float* qx, const float* qy, const float* qr,
+                         const int32_t* minl, const int32_t* maxl, const uint8_t* qdesc, int mode, const uint8_t* active, const int32_t* qlevel,
+                         const uint8_t* qflag, uint8_t* flag, float nnratio, int32_t* out, int n_out)
+{
+    std::vector<int32_t> d0, d1, d2;
+    int cap = 64;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        int rc = window_run(c, f, nq, qx, qy, qr, minl, maxl, qdesc, cap, 1, d0, d1, d2);
+        if (rc) return rc;
+        WindowBufs& W = *c->match->win;
+        hipStream_t st = c->stream;
+        auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+            CCM_RESERVE(c, b, std::max<size_t>(bytes, 16));
+            if (bytes) CCM_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+            return CCM_OK;
+        };
+        if ((rc = up(W.act, active, (size_t)nq)) || (rc = up(W.qflag, qflag, (size_t)nq)) || (rc = up(W.flag, flag, (size_t)f->n))) return rc;
+        if (qlevel && (rc = up(W.qlvl, qlevel, (size_t)nq * 4))) return rc;
+        CCM_RESERVE(c, W.out, std::max<size_t>((size_t)n_out * 4, 16)); CCM_RESERVE(c, W.status, 16);
+        CCM_HIP(c, hipMemsetAsync(W.out.p, 0xFF, (size_t)n_out * 4, st));
+        GreedyArgs A{ nq, f->n, cap, W.ci.as<int>(), W.cd.as<int>(), W.cn.as<int>(), W.act.as<uint8_t>(), qlevel ? W.qlvl.as<int>() : nullptr,
+                      W.oct.as<int>(), W.qflag.as<uint8_t>(), W.flag.as<uint8_t>(), nnratio, W.out.as<int>(), W.status.as<int>() };
+        if (match_launch_window_greedy(st, mode, A)) return ccm_fail(c, CCM_E_DEVICE, "k_window_greedy: LDS request refused");
+        CCM_HIP(c, hipGetLastError());
+        int status[3] = { 0, 0, 0 };
+        CCM_HIP(c, hipMemcpyAsync(status, W.status.p, 12, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        if (status[0] < 0) { cap = status[1]; continue; }                        // rare: a denser window than expected
+        CCM_HIP(c, hipMemcpyAsync(out, W.out.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipMemcpyAsync(flag, W.flag.p, (size_t)f->n, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        return status[0];
+    }
+    return ccm_fail(c, CCM_E_CAPACITY, "window candidate lists keep overflowing");
+}
+
 void match_window_free(WindowBufs* w)
 {
     if (!w) return;
-    DevBuf* all[] = { &w->kx, &w->ky, &w->oct, &w->desc, &w->cfirst, &w->citems, &w->qx, &w->qy, &w->qr, &w->minl, &w->maxl, &w->qdesc, &w->ci, &w->cd, &w->cn };
+    DevBuf* all[] = { &w->kx, &w->ky, &w->oct, &w->desc, &w->cfirst, &w->citems, &w->qx, &w->qy, &w->qr, &w->minl, &w->maxl, &w->qdesc, &w->ci, &w->cd, &w->cn,
+                      &w->sel_i, &w->sel_d, &w->is2, &w->act, &w->qlvl, &w->qflag, &w->flag, &w->out, &w->status };
     for (DevBuf* b : all) b->release();
     delete w;
 }
@@ -374,6 +448,10 @@ int ccm_search_by_projection(ccm_ctx* c, const ccm_frame_grid* f, const float* s
         qr[m] = r * scale_factors[level[m]];
         minl[m] = level[m] - 1; maxl[m] = level[m];
     }
+    static const bool host_accept = getenv("CCM_WINDOW_HOST_ACCEPT") && atoi(getenv("CCM_WINDOW_HOST_ACCEPT")) != 0;   // test switch
+    if (!host_accept && match_window_greedy_lds(f->n, n_mp) <= kGreedyLdsMax)
+        return window_greedy(c, f, n_mp, proj_x, proj_y, qr.data(), minl.data(), maxl.data(), mp_desc, 0, in_view, nullptr, mp_has_obs, occupied,
+                             nnratio, match, f->n);
     int cap = 64;
     std::vector<int32_t> ci, cd, cn;
     for (;;) {
@@ -553,37 +631,23 @@ int ccm_fuse_select(ccm_ctx* c, const ccm_frame_grid* kf, const float* scale_fac
     for (int m = 0; m < n_mp; m++) { best_idx[m] = -1; best_dist[m] = 256; }
     if (n_mp == 0 || kf->n == 0) return CCM_OK;
     CCM_HIP(c, hipSetDevice(c->device));
-    std::vector<float> qr(n_mp); std::vector<int32_t> none(n_mp, -1);
-    for (int m = 0; m < n_mp; m++) qr[m] = valid[m] ? th * scale_factors[level[m]] : -1.f;       // :909 / :1068
-    int cap = 64;
-    std::vector<int32_t> ci, cd, cn;
-    for (;;) {
-        int rc = window_candidates(c, kf, n_mp, u, v, qr.data(), none.data(), none.data(), mp_desc, cap, ci, cd, cn);
-        if (rc) return rc;
-        int mx = 0;
-        for (int k : cn) mx = std::max(mx, k);
-        if (mx <= cap) break;
-        cap = mx;
-    }
+    std::vector<float> qr(n_mp); std::vector<int32_t> lo(n_mp), hi(n_mp);
+    int n_levels = 1;
     for (int m = 0; m < n_mp; m++) {
-        if (!valid[m]) continue;
-        const int lvl = level[m];
-        int bestDist = 256, bestIdx = -1;
-        for (int k = 0; k < cn[m]; k++) {
-            const int idx = ci[(size_t)m * cap + k];
-            const int kpLevel = kf->kp_octave[idx];
-            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
-            if (chi2_check) {
-                const float ex = u[m] - kf->kp_x[idx], ey = v[m] - kf->kp_y[idx];
-                const float e2 = ex * ex + ey * ey;
-                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
-            }
-            const int dist = cd[(size_t)m * cap + k];
-            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-        }
-        best_dist[m] = bestDist;
-        if (bestDist <= accept_th) best_idx[m] = bestIdx;                       // TH_LOW (Fuse) / TH_HIGH (SearchBySim3)
+        qr[m] = valid[m] ? th * scale_factors[level[m]] : -1.f;                                  // :909 / :1068
+        lo[m] = level[m] - 1; hi[m] = level[m];                                                  // :925-926 kpLevel in [level - 1, level]
     }
+    for (int i = 0; i < kf->n; i++) n_levels = std::max(n_levels, kf->kp_octave[i] + 1);
+    // the whole selection runs on the device (k_window_select): one (index, distance) per map point comes back, no candidate list
+    std::vector<int32_t> d0, d1, d2;
+    int rc = window_run(c, kf, n_mp, u, v, qr.data(), lo.data(), hi.data(), mp_desc, 0, 2, d0, d1, d2, chi2_check ? inv_level_sigma2 : nullptr,
+                        n_levels, accept_th);
+    if (rc) return rc;
+    WindowBufs& W = *c->match->win;
+    CCM_HIP(c, hipMemcpyAsync(best_idx, W.sel_i.p, (size_t)n_mp * 4, hipMemcpyDeviceToHost, c->stream));
+    CCM_HIP(c, hipMemcpyAsync(best_dist, W.sel_d.p, (size_t)n_mp * 4, hipMemcpyDeviceToHost, c->stream));
+    CCM_HIP(c, hipStreamSynchronize(c->stream));
+    for (int m = 0; m < n_mp; m++) if (!valid[m]) { best_idx[m] = -1; best_dist[m] = 256; }
     return CCM_OK;
 }
 
@@ -625,6 +689,9 @@ int ccm_search_by_projection_sim3(ccm_ctx* c, const ccm_frame_grid* kf, const fl
     CCM_HIP(c, hipSetDevice(c->device));
     std::vector<float> qr(n_mp); std::vector<int32_t> none(n_mp, -1);
     for (int m = 0; m < n_mp; m++) qr[m] = valid[m] ? th * scale_factors[level[m]] : -1.f;       // :380
+    static const bool host_accept = getenv("CCM_WINDOW_HOST_ACCEPT") && atoi(getenv("CCM_WINDOW_HOST_ACCEPT")) != 0;   // test switch
+    if (!host_accept && match_window_greedy_lds(kf->n, n_mp) <= kGreedyLdsMax)
+        return window_greedy(c, kf, n_mp, u, v, qr.data(), none.data(), none.data(), mp_desc, 1, valid, level, observed, matched, 0.f, best_idx, n_mp);
     int cap = 64;
     std::vector<int32_t> ci, cd, cn;
     for (;;) {

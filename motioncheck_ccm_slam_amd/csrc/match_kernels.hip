@@ -517,6 +517,198 @@ __global__ __launch_bounds__(256) void k_window_candidates(WinGrid G, int nq, co
     }
     if (lane == 0) cand_n[q] = n;
 }
+// ---- device-side acceptance of the windowed matchers: no candidate list leaves the GPU.
+// k_window_select: the selection loop of ORBmatcher::Fuse, both overloads (ORBmatcher.cpp:914-955, :1072-1100), and of
+// SearchBySim3 (:1196-1245): the same window walk as k_window_candidates, but every lane keeps the best (distance, visiting
+// position) of the candidates it filters and the wave reduces to ONE (index, distance) per query.  "First of equal distances
+// wins" (the reference's strict `dist < bestDist` in visiting order) = minimum of distance * 2^32 + position.
+__global__ __launch_bounds__(256) void k_window_select(WinGrid G, int nq, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                       const float* __restrict__ qr, const int* __restrict__ min_level,
+                                                       const int* __restrict__ max_level, const uint8_t* __restrict__ qdesc,
+                                                       const float* __restrict__ inv_sigma2, int accept_th,
+                                                       int* __restrict__ best_idx, int* __restrict__ best_dist)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const float x = qx[q], y = qy[q], r = qr[q];
+    const int minL = min_level[q], maxL = max_level[q];
+    unsigned long long best = ~0ull; int bidx = -1;
+    int n = 0;
+    if (r >= 0.f) {
+        const int nMinCellX = max(0, (int)floorf((x - G.min_x - r) * G.inv_w));
+        const int nMaxCellX = min(G.cols - 1, (int)ceilf((x - G.min_x + r) * G.inv_w));
+        const int nMinCellY = max(0, (int)floorf((y - G.min_y - r) * G.inv_h));
+        const int nMaxCellY = min(G.rows - 1, (int)ceilf((y - G.min_y + r) * G.inv_h));
+        if (nMinCellX < G.cols && nMaxCellX >= 0 && nMinCellY < G.rows && nMaxCellY >= 0) {
+            const uint4* qd = reinterpret_cast<const uint4*>(qdesc) + 2 * (long long)q;
+            const uint4 a0 = qd[0], a1 = qd[1];
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                const int k0 = G.cell_first[ix * G.rows + nMinCellY], k1 = G.cell_first[ix * G.rows + nMaxCellY + 1];
+                for (int base = k0; base < k1; base += 64) {
+                    const int k = base + lane;
+                    bool in_window = false, keep = false; int i = 0;
+                    if (k < k1) {
+                        i = G.cell_items[k];
+                        const float dx = G.kx[i] - x, dy = G.ky[i] - y;
+                        in_window = fabsf(dx) < r && fabsf(dy) < r;           // GetFeaturesInArea is called without level limits here
+                        const int o = G.oct[i];
+                        keep = in_window && !(o < minL || o > maxL);           // :925-926 / :1081-1082 kpLevel in [level-1, level]
+                        if (keep && inv_sigma2) {                              // :929-937: chi2 of the reprojection, Fuse(pKF, vpMapPoints) only
+                            const float ex = x - G.kx[i], ey = y - G.ky[i];
+                            const float e2 = ex * ex + ey * ey;
+                            if ((double)(e2 * inv_sigma2[o]) > 5.99) keep = false;
+                        }
+                    }
+                    const unsigned long long m = __ballot(in_window);
+                    if (keep) {
+                        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                        const uint4* b = reinterpret_cast<const uint4*>(G.desc) + 2 * (long long)i;
+                        const unsigned long long key = ((unsigned long long)ham256(a0, a1, b[0], b[1]) << 32) | (unsigned)pos;
+                        if (key < best) { best = key; bidx = i; }
+                    }
+                    n += __popcll(m);
+                }
+            }
+        }
+    }
+    unsigned long long wbest = best;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(wbest, d, 64); wbest = o < wbest ? o : wbest; }
+    const unsigned long long owner = __ballot(best == wbest && bidx >= 0);
+    int idx = -1, dist = 256;
+    if (owner) { idx = __shfl(bidx, __ffsll((long long)owner) - 1, 64); dist = (int)(wbest >> 32); }
+    if (lane == 0) { best_dist[q] = dist; best_idx[q] = dist <= accept_th ? idx : -1; }
+}
+void match_launch_window_select(hipStream_t s, const WinGrid& G, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
+                                const int* maxl, const uint8_t* qdesc, const float* inv_sigma2, int accept_th, int* best_idx, int* best_dist)
+{
+    hipLaunchKernelGGL(k_window_select, dim3((nq + 3) / 4), dim3(256), 0, s, G, nq, qx, qy, qr, minl, maxl, qdesc, inv_sigma2, accept_th, best_idx, best_dist);
+}
+
+// k_window_greedy: the ORDER-DEPENDENT acceptance of SearchByProjection(Frame&, vpMapPoints) (ORBmatcher.cpp:71-148, MODE 0) and
+// SearchByProjection(pKF, Scw, vpPoints, vpMatched) (:308-446, MODE 1) on the candidate lists k_window_candidates left in HBM.
+// The reference visits the map points one after the other and a point's choice depends on which features earlier points have
+// taken (`occupied` / `vpMatched`).  Equivalent parallel form: in every round each unresolved point claims its still-free
+// candidates with atomicMin(claim[feature], point); a point that holds the claim on ALL of them is the earliest unresolved point
+// touching any of its candidates, so nothing can change its inputs any more: it decides exactly as the sequential loop would.
+// Points resolved in one round have disjoint candidates (no write conflict); the lowest unresolved point always resolves, so
+// the loop ends, and after WG_MAX_ROUNDS (chains of points sharing one window) one thread finishes the rest in order.
+// One workgroup; claim / flag / resolved live in LDS.
+struct GreedyArgs {
+    int nq, n, cap;
+    const int* ci; const int* cd; const int* cn;      // candidate lists [nq][cap], counts
+    const uint8_t* active;                            // mbTrackInView && !isBad  /  passed the projection tests
+    const int* qlevel; const int* oct;                // predicted level per point, octave per feature
+    const uint8_t* qflag;                             // Observations() > 0  /  already observed in the keyframe
+    uint8_t* flag;                                    // in/out per feature: occupied / matched
+    float nnratio;
+    int* out;                                         // MODE 0: match[feature] = point; MODE 1: best_idx[point] = feature
+    int* status;                                      // [0] matches (or -1: a list overflowed), [1] longest list, [2] rounds
+};
+#define WG_MAX_ROUNDS 48
+template <int MODE>
+__device__ __forceinline__ int wg_decide(const GreedyArgs& A, int m, uint8_t* flag)
+{
+    const int c = A.cn[m];
+    const int* ci = A.ci + (long long)m * A.cap; const int* cd = A.cd + (long long)m * A.cap;
+    if (MODE == 0) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < c; k++) {
+            const int idx = ci[k];
+            if (flag[idx]) continue;
+            const int dist = cd[k];
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = A.oct[idx]; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = A.oct[idx]; bestDist2 = dist; }
+        }
+        if (bestDist <= 100) {                                                  // TH_HIGH
+            if (bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2) return 0;
+            A.out[bestIdx] = m;
+            flag[bestIdx] = A.qflag[m];
+            return 1;
+        }
+        return 0;
+    } else {
+        const int lvl = A.qlevel[m];
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < c; k++) {
+            const int idx = ci[k];
+            if (flag[idx]) continue;                                            // :394
+            const int kpLevel = A.oct[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            const int dist = cd[k];
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= 50) {                                                   // TH_LOW
+            A.out[m] = bestIdx;
+            if (!A.qflag[m]) { flag[bestIdx] = 1; return 1; }                   // :436-440
+        }
+        return 0;
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
+{
+    extern __shared__ int wg_lds[];
+    int* claim = wg_lds;                                            // [n]
+    uint8_t* flag = reinterpret_cast<uint8_t*>(claim + A.n);        // [n]
+    uint8_t* resolved = flag + ((A.n + 3) & ~3);                    // [nq]
+    __shared__ int s_left, s_count, s_maxcn;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_count = 0; s_maxcn = 0; }
+    for (int i = tid; i < A.n; i += 1024) flag[i] = A.flag[i];
+    __syncthreads();
+    int mx = 0;
+    for (int m = tid; m < A.nq; m += 1024) { const int c = A.cn[m]; mx = max(mx, c); resolved[m] = (!A.active[m] || c == 0) ? 1 : 0; }
+    atomicMax(&s_maxcn, mx);
+    __syncthreads();
+    if (s_maxcn > A.cap) { if (tid == 0) { A.status[0] = -1; A.status[1] = s_maxcn; A.status[2] = 0; } return; }   // the host retries with longer lists
+    int round = 0;
+    for (;; round++) {
+        for (int i = tid; i < A.n; i += 1024) claim[i] = 0x7FFFFFFF;
+        if (tid == 0) s_left = 0;
+        __syncthreads();
+        if (round >= WG_MAX_ROUNDS) {
+            if (tid == 0) { int cnt = 0; for (int m = 0; m < A.nq; m++) if (!resolved[m]) cnt += wg_decide<MODE>(A, m, flag); s_count += cnt; }
+            __syncthreads();
+            break;
+        }
+        for (int m = tid; m < A.nq; m += 1024) {
+            if (resolved[m]) continue;
+            const int c = A.cn[m]; const int* ci = A.ci + (long long)m * A.cap;
+            for (int k = 0; k < c; k++) { const int idx = ci[k]; if (!flag[idx]) atomicMin(&claim[idx], m); }
+        }
+        __syncthreads();
+        int mine = 0, left = 0;
+        for (int m = tid; m < A.nq; m += 1024) {
+            if (resolved[m]) continue;
+            const int c = A.cn[m]; const int* ci = A.ci + (long long)m * A.cap;
+            bool fin = true;
+            for (int k = 0; k < c && fin; k++) { const int idx = ci[k]; fin = flag[idx] || claim[idx] == m; }
+            if (fin) { mine += wg_decide<MODE>(A, m, flag); resolved[m] = 1; } else left++;
+        }
+        if (mine) atomicAdd(&s_count, mine);
+        if (left) atomicAdd(&s_left, left);
+        __syncthreads();
+        if (s_left == 0) break;
+        __syncthreads();                                             // everybody has read s_left before it is reset
+    }
+    for (int i = tid; i < A.n; i += 1024) A.flag[i] = flag[i];
+    if (tid == 0) { A.status[0] = s_count; A.status[1] = s_maxcn; A.status[2] = round; }
+}
+size_t match_window_greedy_lds(int n, int nq) { return (size_t)4 * n + ((n + 3) & ~3) + nq + 16; }
+int match_launch_window_greedy(hipStream_t s, int mode, const GreedyArgs& A)
+{
+    const size_t lds = match_window_greedy_lds(A.n, A.nq);
+    if (mode == 0) {
+        if (hipFuncSetAttribute((const void*)k_window_greedy<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_window_greedy<0>, dim3(1), dim3(1024), lds, s, A);
+    } else {
+        if (hipFuncSetAttribute((const void*)k_window_greedy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_window_greedy<1>, dim3(1), dim3(1024), lds, s, A);
+    }
+    return 0;
+}
+
 void match_launch_window(hipStream_t s, const WinGrid& G, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
                          const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn)
 {

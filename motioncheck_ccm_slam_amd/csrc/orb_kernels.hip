@@ -23,6 +23,36 @@ __device__ __forceinline__ unsigned fc_u(fc_us2 x) { return __builtin_bit_cast(u
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// XCD-aware work order for 2-D grids (x = item of a frame, y = frame).  Workgroups are dealt to the 8 XCDs round-robin by their
+// linear id, and each XCD has its own 4 MiB L2: with the natural order the bands / keypoints of ONE frame are spread over all
+// eight, so every 128-byte line of the frame's pyramid that two neighbouring items share crosses the fabric once per XCD (the
+// round-1 counters showed 2.1x the algorithmic bytes for k_fast_cells).  This bijection hands XCD k a CONTIGUOUS range of
+// (frame, item) pairs instead -- whole frames -- so a line is fetched once and then found in that XCD's L2.  Speed only: the
+// result does not depend on where a workgroup runs.  on == 0 keeps the natural order, 1 = one contiguous range per XCD,
+// C > 1 = chunks of C consecutive items per XCD, dealt cyclically (CCM_ORB_XCD / _FC / _OD, for A/B timing).
+__device__ __forceinline__ void xcd_work_item(int on, int& x, int& y)
+{
+    x = (int)blockIdx.x; y = (int)blockIdx.y;
+    if (!on) return;
+    const unsigned gx = gridDim.x, total = gx * gridDim.y;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    unsigned w;
+    if (on == 1) {                                                         // each XCD one contiguous eighth of the items
+        const unsigned xcd = lin & 7u, q = total >> 3, rem = total & 7u;
+        w = xcd * q + (xcd < rem ? xcd : rem) + (lin >> 3);                // start of the XCD's range + its (lin / 8)-th slot
+    } else {                                                               // chunk-cyclic: chunks of `on` consecutive items go to one XCD, chunk c to XCD c % 8
+        const unsigned C = (unsigned)on, span = 8u * C;
+        const unsigned full = total - total % span;                        // the ragged tail keeps the natural order
+        if (lin >= full) w = lin;
+        else {
+            const unsigned xcd = lin & 7u, j = lin >> 3;                   // the XCD's j-th workgroup overall
+            const unsigned super = j / C, within = j - super * C;         // j-th = `within` of the XCD's chunk number `super`
+            w = (super * 8u + xcd) * C + within;
+        }
+    }
+    y = (int)(w / gx); x = (int)(w - (unsigned)y * gx);
+}
+
 // inclusive wave prefix sum
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
@@ -430,11 +460,13 @@ __device__ __forceinline__ int fc_mbcnt(unsigned long long m, int base)
 }
 template <bool PACKED>
 __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
-                                                    unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl)
+                                                    unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl, int xcd_on)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
-    const OrbBand B = bands[blockIdx.x];
-    const int f = blockIdx.y + g.frame0, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    int wx, wy;
+    xcd_work_item(xcd_on, wx, wy);
+    const OrbBand B = bands[wx];
+    const int f = wy + g.frame0, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const OrbLevel& L = g.lv[B.level];
     const int P = B.pitch, bh = B.bh, PW = P >> 2;
     uint8_t* T = fc_smem;                                   // pixels  [bh][P]
@@ -1107,7 +1139,7 @@ __device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc
 __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
                                                      const int* __restrict__ sel_count,
                                                      ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                     int* __restrict__ counts, int max_per_image, int* __restrict__ status)
+                                                     int* __restrict__ counts, int max_per_image, int* __restrict__ status, int xcd_on)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[OD_WAVES][OD_WAVE_LDS_PAD];
     // IC_Angle weights per |v| and patch dword k (columns 4k..4k+3, u = column - 21):
@@ -1125,7 +1157,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const OrbGeom g, 
     }
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int slot = blockIdx.x * OD_WAVES + wv, f = blockIdx.y + g.frame0;
+    int wx, wy;
+    xcd_work_item(xcd_on, wx, wy);
+    const int slot = wx * OD_WAVES + wv, f = wy + g.frame0;
     if (slot >= g.out_per_frame) return;
     // slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
     int level = 0;
@@ -1274,8 +1308,9 @@ void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* c
 {
     static const bool packed = !(getenv("CCM_FC_PACKED") && atoi(getenv("CCM_FC_PACKED")) == 0);
     static const int abl = getenv("CCM_FC_ABL") ? atoi(getenv("CCM_FC_ABL")) : 0;     // timing ablations only (results are wrong)
-    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
-    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl);
+    static const int xcd_on = getenv("CCM_ORB_XCD_FC") ? atoi(getenv("CCM_ORB_XCD_FC")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 1);
+    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
+    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
 }
 size_t orb_fast_cells_lds(int pitch, int bh, int surv_cap) { return fc_lds_bytes(pitch, bh, surv_cap); }
 void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,
@@ -1289,6 +1324,7 @@ void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_fra
                             const int* sel_count, ccm_keypoint* kps, uint8_t* desc, int* counts, int max_per_image,
                             int* status)
 {
+    static const int xcd_on = getenv("CCM_ORB_XCD_OD") ? atoi(getenv("CCM_ORB_XCD_OD")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 1);
     hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + OD_WAVES - 1) / OD_WAVES, nframes), dim3(64 * OD_WAVES), 0, s,
-                       g_dev, sel, sel_count, kps, desc, counts, max_per_image, status);
+                       g_dev, sel, sel_count, kps, desc, counts, max_per_image, status, xcd_on);
 }

@@ -124,9 +124,10 @@ class Optimizer:
         a = np.ascontiguousarray
         s3 = a(sim3, "f8").copy().reshape(-1, 8); fx = a(fixed, np.uint8); ei = a(edge_i, "i4"); ej = a(edge_j, "i4"); ms = a(measurement, "f8")
         p = _lib.ptr
-        g = _lib.EssentialGraph(len(s3), p(s3), p(fx), int(bFixScale), len(ei), p(ei), p(ej), p(ms), int(iterations), 0, 0.0, 0.0)
+        g = _lib.EssentialGraph(len(s3), p(s3), p(fx), int(bFixScale), len(ei), p(ei), p(ej), p(ms), int(iterations), 0, 0.0, 0.0, 0, 0, 0)
         ctx.check(lib.ccm_optimize_essential_graph(ctx.handle, C.byref(g)))
-        return s3, dict(iterations_done=g.iterations_done, chi2_initial=g.chi2_initial, chi2_final=g.chi2_final)
+        return s3, dict(iterations_done=g.iterations_done, chi2_initial=g.chi2_initial, chi2_final=g.chi2_final,
+                        factor_blocks=g.factor_blocks, factor_rounds=g.factor_rounds, solver_bytes=g.solver_bytes)
 
     @staticmethod
     def CorrectMapPoints(points, ref_vertex, sim3_before, sim3_after, ctx=None):

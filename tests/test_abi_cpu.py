@@ -125,3 +125,14 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lccm_hot", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.split() == ["5", "217", "28"], out.stdout + out.stderr
+
+
+def test_library_links_no_dense_solver_library():
+    """The product library carries its own solvers (block Gauss-Jordan, PCG, block-sparse Cholesky): rocSOLVER / rocBLAS, whose
+    dpotrf the builder measured to return wrong factors when the GPU is shared, are not even linked."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    needed = re.findall(r"\(NEEDED\)\s+Shared library: \[([^\]]+)\]", out)
+    assert needed and not [n for n in needed if "rocsolver" in n or "rocblas" in n], needed
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rocsolver_" not in syms and "rocblas_" not in syms

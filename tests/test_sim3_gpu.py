@@ -67,6 +67,7 @@ def test_essential_graph_matches_oracle(ctx, oracle, n, fix_scale):
     # tolerance: the contract's 1e-5 on pose updates; numeric Jacobians (delta 1e-9) on both sides
     assert np.abs(out - ref).max() < 1e-6, np.abs(out - ref).max()
     assert (out[0] == sim3[0]).all() and info["chi2_final"] < 0.05 * info["chi2_initial"]
+    assert info["factor_blocks"] >= n - 1 and info["factor_rounds"] >= 1
     if fix_scale:
         assert np.allclose(out[:, 7], sim3[:, 7], rtol=0, atol=0)
     # map point correction: points attached to reference keyframes follow them
@@ -88,5 +89,9 @@ def test_essential_graph_2000_keyframes_properties(ctx, oracle):
     sim3, fixed, ei, ej, meas, truth = make_pose_graph(oracle, rng, n=2000, drift=0.002, scale_drift=0.0005, covis=3)
     out, info = Optimizer.OptimizeEssentialGraph(sim3, fixed, ei, ej, meas, False, 20, ctx=ctx)
     assert info["chi2_final"] < 0.05 * info["chi2_initial"] and (out[0] == sim3[0]).all()
+    # block-sparse solve (src/Optimizer.cpp:1072-1074: BlockSolver_7_3 + sparse Cholesky): no dense 13,993^2 matrix (1.57 GB) any more
+    assert info["solver_bytes"] < 100e6 and info["factor_blocks"] >= 1999 + len(ei) - 8 and 0 < info["factor_rounds"] < 400, info
+    again, info2 = Optimizer.OptimizeEssentialGraph(sim3, fixed, ei, ej, meas, False, 20, ctx=ctx)
+    assert (again == out).all() and info2["chi2_final"] == info["chi2_final"]                  # fixed summation orders: bit-reproducible
     loop_err = oracle.sim3_log(oracle.sim3_mul(oracle.sim3_mul(meas[-1], out[ei[-1]]), oracle.sim3_inverse(out[ej[-1]])))
     assert np.abs(loop_err).max() < 0.05

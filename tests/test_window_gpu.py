@@ -235,3 +235,51 @@ def test_search_for_triangulation(ctx, oracle):
         rn, r12 = oracle.search_for_triangulation(d1, node1, has1, f1.kx, f1.ky, k1["angle"], d2, node2, has2, x2, y2, a2, o2, F12, ex_, ey_, sf, sig2, ori)
         assert n == rn and (m12 == r12).all()
         assert n > 100 and (m12[has1] == -1).all()
+
+
+def test_device_acceptance_chains_and_large_batches(ctx, oracle):
+    """The order-dependent acceptance on the device (k_window_greedy) at its corners:
+    (a) 3000 map points projected into ONE small region: every point competes with every earlier one, so the claim rounds
+        resolve one point at a time and the kernel's sequential tail (after 48 rounds) takes over;
+    (b) 20,000 map points against one keyframe (server-side map matching): no candidate list leaves the GPU.
+    Both must equal the reference's sequential loop (the oracle) exactly, for SearchByProjection(Frame, points) and for
+    SearchByProjection(KF, Scw)."""
+    fr, sf, kps, desc = _frame(ctx, 10)
+    n = len(fr.kx)
+    rng = np.random.default_rng(21)
+    m = ORBmatcher(0.8, ctx=ctx)
+    # (a) a chain
+    nmp = 3000
+    centre = np.array([fr.kx[n // 2], fr.ky[n // 2]])
+    px = (centre[0] + rng.normal(0, 6, nmp)).astype("f4"); py = (centre[1] + rng.normal(0, 6, nmp)).astype("f4")
+    near = np.argsort((fr.kx - centre[0]) ** 2 + (fr.ky - centre[1]) ** 2)[:40]
+    src = near[rng.integers(0, len(near), nmp)]
+    mp_desc = desc[src] ^ np.packbits(rng.random((nmp, 256)) < 0.04, axis=1, bitorder="little")
+    level = np.clip(fr.oct[src] + rng.integers(0, 2, nmp), 0, 7)
+    ones = np.ones(nmp, bool)
+    has_obs = rng.random(nmp) < 0.7
+    occ0 = np.zeros(n, bool)
+    nm, match, occ = m.SearchByProjection(fr, sf, ones, level, np.full(nmp, 0.9, "f4"), px, py, mp_desc, has_obs, occ0, 3.0)
+    rn, rmatch, rocc = oracle.search_by_projection(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, ones, level,
+                                                   np.full(nmp, 0.9, "f4"), px, py, mp_desc, has_obs, occ0, 3.0, 0.8)
+    assert nm == rn and (match == rmatch).all() and (occ == rocc).all() and nm > 20
+    observed = rng.random(nmp) < 0.2
+    n2, bi, mt = m.SearchByProjectionSim3(fr, sf, ones, px, py, level, mp_desc, observed, occ0, 6.0)
+    r2, rbi, rmt = oracle.search_by_projection_sim3(fr, sf, ones, px, py, level, mp_desc, observed, occ0, 6.0)
+    assert n2 == r2 and (bi == rbi).all() and (mt == rmt).all() and n2 > 10
+    # (b) a large batch
+    nmp = 20000
+    src = rng.integers(0, n, nmp)
+    mp_desc = desc[src] ^ np.packbits(rng.random((nmp, 256)) < 0.05, axis=1, bitorder="little")
+    px = (fr.kx[src] + rng.normal(0, 2.0, nmp)).astype("f4"); py = (fr.ky[src] + rng.normal(0, 2.0, nmp)).astype("f4")
+    level = np.clip(fr.oct[src] + rng.integers(0, 2, nmp), 0, 7)
+    valid = rng.random(nmp) < 0.95
+    observed = rng.random(nmp) < 0.1
+    matched = rng.random(n) < 0.1
+    n2, bi, mt = m.SearchByProjectionSim3(fr, sf, valid, px, py, level, mp_desc, observed, matched, 8.0)
+    r2, rbi, rmt = oracle.search_by_projection_sim3(fr, sf, valid, px, py, level, mp_desc, observed, matched, 8.0)
+    assert n2 == r2 and (bi == rbi).all() and (mt == rmt).all() and n2 > 300
+    is2 = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx).GetInverseScaleSigmaSquares()
+    bi, bd = m.FuseSelect(fr, sf, is2, valid, px, py, level, mp_desc, 3.0, True)
+    rbi, rbd = oracle.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, valid, px, py, level, mp_desc, 3.0, True)
+    assert (bi == rbi).all() and (bd == rbd).all() and (bi >= 0).sum() > 5000

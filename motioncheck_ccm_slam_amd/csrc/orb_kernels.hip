@@ -50,7 +50,10 @@ __device__ __forceinline__ void xcd_work_item(int on, int& x, int& y)
             w = (super * 8u + xcd) * C + within;
         }
     }
-    y = (int)(w / gx); x = (int)(w - (unsigned)y * gx);
+    // w / gx without the ~40-instruction integer division in front of every workgroup's first load (w < 2^24: exact in float)
+    unsigned q = (unsigned)((float)w * __frcp_rn((float)gx));
+    if (q * gx > w) q--; else if ((q + 1u) * gx <= w) q++;
+    y = (int)q; x = (int)(w - q * gx);
 }
 
 // inclusive wave prefix sum
@@ -1308,7 +1311,10 @@ void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* c
 {
     static const bool packed = !(getenv("CCM_FC_PACKED") && atoi(getenv("CCM_FC_PACKED")) == 0);
     static const int abl = getenv("CCM_FC_ABL") ? atoi(getenv("CCM_FC_ABL")) : 0;     // timing ablations only (results are wrong)
-    static const int xcd_on = getenv("CCM_ORB_XCD_FC") ? atoi(getenv("CCM_ORB_XCD_FC")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 1);
+    // default 0 for this kernel: co-locating neighbouring bands on one XCD cuts its fabric reads 2.2x (285 -> 128 MiB per launch, = the
+    // algorithmic bytes) but the kernel, which is not bandwidth-bound, runs 3-5 % slower with every co-locating order tried
+    // (profiles/r02_xcd_order.txt); k_orient_desc gains from it and uses it
+    static const int xcd_on = getenv("CCM_ORB_XCD_FC") ? atoi(getenv("CCM_ORB_XCD_FC")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 0);
     if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
     else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
 }

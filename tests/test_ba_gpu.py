@@ -44,6 +44,21 @@ def test_gba_small_and_medium(ctx, oracle):
         assert np.isclose(r["chi2_final"], ref["chi2_final"], rtol=1e-8)
 
 
+def test_edge_order_does_not_matter(ctx):
+    """The library orders the observations by (landmark, keyframe) itself (sorted input is detected in one pass, anything else goes
+    through a linear-time counting sort): a shuffled edge list must give bit-identical poses, points and the outlier flags of the
+    SAME observations."""
+    g = synth.local_ba_graph()
+    r = Optimizer.LocalBundleAdjustmentClient(g, ctx=ctx)
+    rng = np.random.default_rng(3)
+    o = rng.permutation(len(g["edge_pose"]))
+    g2 = dict(g, edge_pose=g["edge_pose"][o], edge_point=g["edge_point"][o], obs=g["obs"][o], info=g["info"][o])
+    r2 = Optimizer.LocalBundleAdjustmentClient(g2, ctx=ctx)
+    assert (r2["poses"] == r["poses"]).all() and (r2["points"] == r["points"]).all()
+    assert (r2["outlier"] == r["outlier"][o]).all() and r["outlier"].sum() > 0
+    assert r2["iterations_done"] == r["iterations_done"] and r2["chi2_final"] == r["chi2_final"]
+
+
 def test_noise_free_graph_is_recovered(ctx):
     g = synth.local_ba_graph(n_free=8, n_fixed=3, n_points=600, seed=31, noise=False)
     r = Optimizer.BundleAdjustmentClient(g, 25, bRobust=False, ctx=ctx)

@@ -51,6 +51,9 @@ int  orc_orb_extract(const orc_orb_params*, const uint8_t* img, int w, int h, in
                      uint8_t* level_out, size_t level_out_bytes,
                      int cand_level, int32_t* cand_xy, int32_t* cand_score, int cand_max, int32_t* cand_n);
 
+/* all-core CPU baseline driver (pthreads over frames, then over consecutive pairs); seconds[0] extraction, [1] matching */
+long orc_bench_extract_match_mt(const orc_orb_params*, const uint8_t* imgs, int n, int w, int h, int threads, double* seconds);
+
 /* ---- matcher ---- */
 int  orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
 void orc_hamming_match(const uint8_t* q, int nq, const uint8_t* t, int nt,

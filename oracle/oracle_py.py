@@ -398,3 +398,16 @@ def ba_solve_once(g, huber_delta, lam, mode=0):
         return None
     assert P == nfree
     return xp, xl, dict(factor_blocks=int(st[0]), factor_flops=float(st[1]), schur_upper_blocks=int(st[2]))
+
+
+def bench_extract_match_mt(par: OrbParams, frames: np.ndarray, threads: int):
+    """All-core CPU baseline: frames [n,h,w] uint8 dealt to `threads` POSIX threads inside the oracle (no GIL involved), then the
+    n - 1 consecutive pairs.  Returns (keypoints, extraction seconds, matching seconds)."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    sec = np.zeros(2)
+    L = lib()
+    L.orc_bench_extract_match_mt.restype = C.c_long
+    tot = L.orc_bench_extract_match_mt(C.byref(par), _p(frames), n, w, h, int(threads), _p(sec))
+    assert tot >= 0
+    return int(tot), float(sec[0]), float(sec[1])

@@ -630,3 +630,59 @@ int orc_orb_extract(const orc_orb_params* p, const uint8_t* img, int w, int h, i
     free(cxy); free(csc); free(sel);
     return rc ? rc : total;
 }
+
+/* ------------------------------------------------------------------ all-core CPU baseline (bench.py)
+ * The reference extracts and matches single-threaded per call; a server with many clients would run one call per core.  This
+ * driver deals n frames (then the n - 1 consecutive pairs) to `threads` POSIX threads, each running the same scalar code as above,
+ * and reports wall-clock seconds per phase.  Measurement scaffolding: no Python, no GIL, no per-frame allocation outside the
+ * oracle's own. */
+#include <pthread.h>
+#include <time.h>
+typedef struct {
+    const orc_orb_params* par; const uint8_t* imgs; int n, w, h, threads, tid, max_kps;
+    orc_keypoint* kps; uint8_t* desc; int32_t* counts; int phase;
+} mt_job;
+static void* mt_worker(void* arg)
+{
+    mt_job* j = (mt_job*)arg;
+    if (j->phase == 0) {
+        for (int f = j->tid; f < j->n; f += j->threads) {
+            int32_t dummy = 0;
+            j->counts[f] = orc_orb_extract(j->par, j->imgs + (size_t)f * j->w * j->h, j->w, j->h, j->w, j->kps + (size_t)f * j->max_kps,
+                                           j->desc + (size_t)f * j->max_kps * 32, j->max_kps, 0, 0, -1, 0, 0, 0, &dummy);
+        }
+    } else {
+        int32_t* bi = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)j->max_kps);
+        for (int f = j->tid; f + 1 < j->n; f += j->threads)
+            if (j->counts[f] > 0 && j->counts[f + 1] > 0)
+                orc_hamming_match(j->desc + (size_t)f * j->max_kps * 32, j->counts[f], j->desc + (size_t)(f + 1) * j->max_kps * 32, j->counts[f + 1],
+                                  bi, bi + j->max_kps, bi + 2 * j->max_kps);
+        free(bi);
+    }
+    return 0;
+}
+static double mt_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+/* returns the total keypoint count (or < 0); seconds[0] = extraction, seconds[1] = matching */
+long orc_bench_extract_match_mt(const orc_orb_params* par, const uint8_t* imgs, int n, int w, int h, int threads, double* seconds)
+{
+    if (!par || !imgs || n < 1 || threads < 1) return -1;
+    const int max_kps = par->nfeatures + 4 * par->nlevels + 64;
+    orc_keypoint* kps = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)n * max_kps);
+    uint8_t* desc = (uint8_t*)malloc((size_t)n * max_kps * 32);
+    int32_t* counts = (int32_t*)calloc(n, sizeof(int32_t));
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    mt_job* jobs = (mt_job*)malloc(sizeof(mt_job) * threads);
+    for (int phase = 0; phase < 2; phase++) {
+        const double t0 = mt_now();
+        for (int t = 0; t < threads; t++) {
+            jobs[t] = (mt_job){ par, imgs, n, w, h, threads, t, max_kps, kps, desc, counts, phase };
+            pthread_create(&th[t], 0, mt_worker, &jobs[t]);
+        }
+        for (int t = 0; t < threads; t++) pthread_join(th[t], 0);
+        if (seconds) seconds[phase] = mt_now() - t0;
+    }
+    long total = 0;
+    for (int f = 0; f < n; f++) total += counts[f] > 0 ? counts[f] : 0;
+    free(kps); free(desc); free(counts); free(th); free(jobs);
+    return total;
+}

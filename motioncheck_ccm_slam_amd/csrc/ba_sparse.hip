@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256) void k_sp_to_dense(const double* __restrict__ 
 // blocks between them (consecutive keyframes of a trajectory share most of their landmarks, so these are the strongest
 // off-diagonal blocks of the reduced camera system); its inverse is a dense PCG_CN x PCG_CN matrix per cluster, applied
 // as a mat-vec.  Minv layout: [cluster][PCG_CN][PCG_CN], symmetric.
-#define PCG_CL 8
+#ifndef PCG_CL
+#define PCG_CL 8               // keyframes per cluster (measured round 2: see DESIGN.md, preconditioner study on the GPU)
+#endif
 #ifndef PCG_XCDS
 #define PCG_XCDS 8               // 1 = block rows in dispatch order (round-robin over the XCDs)
 #endif
@@ -335,8 +337,8 @@ __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, 
 __host__ __device__ inline int pcg_agg_clusters(int nfree)
 {
     int agg = PCG_AGG;
-    while (agg < 8 && 6 * ((nfree + PCG_CL * agg - 1) / (PCG_CL * agg)) > PCG_COARSE_MAX) agg *= 2;
-    return agg < 8 ? agg : 8;
+    while (2 * agg * PCG_CL <= 64 && 6 * ((nfree + PCG_CL * agg - 1) / (PCG_CL * agg)) > PCG_COARSE_MAX) agg *= 2;
+    return agg;
 }
 // upper triangle of Ac, row-major with pitch ncp: one workgroup per aggregate pair I <= J, thread =
 // keyframe pair (i, j), the 36 sums reduced over the workgroup in a fixed order (the ranks of a sharded solve must get

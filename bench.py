@@ -238,7 +238,20 @@ def main():
         for i in range(100):
             t1 = time.perf_counter(); ex.extract_batch(one); lat.append(time.perf_counter() - t1)
         lat = np.asarray(lat) * 1e3
+        # the same batch from a page-locked frame pool (ccm_host_register: what a server re-using its buffers would do)
+        reg_ms = None
+        try:
+            ctx.host_register(frames)
+            ex.extract_batch(frames)
+            ts2 = []
+            for _ in range(5):
+                t1 = time.perf_counter(); ex.extract_batch(frames); ts2.append(time.perf_counter() - t1)
+            reg_ms = round(float(np.median(ts2)) * 1e3, 3)
+            ctx.host_unregister(frames)
+        except Exception as e:
+            reg_ms = "failed: %s" % e
         pcie = {"batch256_ms": round(tb_ * 1e3, 3), "batch256_Mfeatures_per_s": round(float(cnt.sum()) / tb_ / 1e6, 2),
+                "batch256_registered_input_ms": reg_ms,
                 "batch256_note": "ccm_orb_extract with pageable host frames in (92 MB) and host keypoints+descriptors out (17 MB); "
                                  "extraction only, no matching; median of 5 calls",
                 "single_frame_latency_ms": {"median": round(float(np.median(lat)), 4), "p90": round(float(np.percentile(lat, 90)), 4),

@@ -57,6 +57,12 @@ enum { CCM_PROF_RESIZE = 0, CCM_PROF_FAST_SCORE, CCM_PROF_CELL_NMS, CCM_PROF_OCT
         * (k_sp_dinv + k_sp_edge_y), the Schur block GEMM (k_sp_schur_blocks), bschur, back-substitution */
        CCM_PROF_BA_LINEARIZE, CCM_PROF_BA_DINV_Y, CCM_PROF_BA_SCHUR_BLOCKS, CCM_PROF_BA_BSCHUR, CCM_PROF_BA_BACKSUB,
        CCM_PROF_COUNT };
+/* Page-lock a host buffer the caller keeps (a frame pool, the cv::Mat a camera driver fills): uploads from it and downloads
+ * into it then go by DMA at the full PCIe rate instead of through the runtime's staging of pageable memory.  Thin wrappers over
+ * hipHostRegister / hipHostUnregister; optional -- every entry point accepts pageable pointers. */
+int ccm_host_register(ccm_ctx*, void* ptr, size_t bytes);
+int ccm_host_unregister(ccm_ctx*, void* ptr);
+
 int ccm_profile_enable(ccm_ctx*, int on);
 int ccm_profile_read(ccm_ctx*, float ms[CCM_PROF_COUNT], int32_t launches[CCM_PROF_COUNT]);
 

@@ -24,7 +24,7 @@ KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), 
 # every symbol include/ccm_hot.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ccm_abi_version", "ccm_create", "ccm_destroy", "ccm_last_error", "ccm_sync", "ccm_stream",
-    "ccm_profile_enable", "ccm_profile_read",
+    "ccm_host_register", "ccm_host_unregister", "ccm_profile_enable", "ccm_profile_read",
     "ccm_orb_tables", "ccm_orb_level_sizes", "ccm_orb_extract", "ccm_orb_extract_dev", "ccm_orb_fetch",
     "ccm_orb_result_dev", "ccm_orb_debug_level", "ccm_orb_debug_candidates",
     "ccm_descriptor_distance", "ccm_hamming_match", "ccm_hamming_match_dev", "ccm_ratio_test", "ccm_match_bow",
@@ -119,6 +119,8 @@ def load():
     lib.ccm_stream.restype = C.c_void_p
     lib.ccm_stream.argtypes = [C.c_void_p]
     vp = C.c_void_p
+    lib.ccm_host_register.argtypes = [vp, vp, C.c_size_t]
+    lib.ccm_host_unregister.argtypes = [vp, vp]
     lib.ccm_profile_enable.argtypes = [vp, C.c_int]
     lib.ccm_profile_read.argtypes = [vp, vp, vp]
     lib.ccm_orb_tables.argtypes = [C.POINTER(OrbParams)] + [vp] * 6
@@ -194,6 +196,13 @@ class Context:
 
     PROF_LABELS = ("k_pyr_resize", "k_fast_score", "k_cell_nms", "k_octree", "k_orient_desc", "k_hamming_bf",
                    "ba_linearize", "ba_dinv_y", "k_sp_schur_blocks", "k_sp_bschur", "k_ba_backsub")
+
+    def host_register(self, arr):
+        """Page-lock a numpy array the caller keeps re-using as an input / output buffer (ccm_host_register)."""
+        self.check(self.lib.ccm_host_register(self.handle, ptr(arr), C.c_size_t(arr.nbytes)))
+
+    def host_unregister(self, arr):
+        self.check(self.lib.ccm_host_unregister(self.handle, ptr(arr)))
 
     def profile(self, on: bool):
         self.check(self.lib.ccm_profile_enable(self.handle, int(on)))

@@ -58,6 +58,22 @@ int ccm_sync(ccm_ctx* c)
 
 void* ccm_stream(ccm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+int ccm_host_register(ccm_ctx* c, void* ptr, size_t bytes)
+{
+    if (!c || !ptr || bytes == 0) return c ? ccm_fail(c, CCM_E_ARG, "bad host buffer") : CCM_E_ARG;
+    CCM_HIP(c, hipSetDevice(c->device));
+    CCM_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return CCM_OK;
+}
+
+int ccm_host_unregister(ccm_ctx* c, void* ptr)
+{
+    if (!c || !ptr) return CCM_E_ARG;
+    CCM_HIP(c, hipSetDevice(c->device));
+    CCM_HIP(c, hipHostUnregister(ptr));
+    return CCM_OK;
+}
+
 int ccm_profile_enable(ccm_ctx* c, int on)
 {
     if (!c) return CCM_E_ARG;

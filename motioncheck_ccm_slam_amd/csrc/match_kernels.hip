@@ -592,7 +592,7 @@ void match_launch_window_select(hipStream_t s, const WinGrid& G, int nq, const f
 // candidates with atomicMin(claim[feature], point); a point that holds the claim on ALL of them is the earliest unresolved point
 // touching any of its candidates, so nothing can change its inputs any more: it decides exactly as the sequential loop would.
 // Points resolved in one round have disjoint candidates (no write conflict); the lowest unresolved point always resolves, so
-// the loop ends, and after WG_MAX_ROUNDS (chains of points sharing one window) one thread finishes the rest in order.
+// the loop ends, and after WG_MAX_ROUNDS (chains of points sharing one window) one wave finishes the rest in order, a candidate per lane.
 // One workgroup; claim / flag / resolved live in LDS.
 struct GreedyArgs {
     int nq, n, cap;
@@ -645,6 +645,57 @@ __device__ __forceinline__ int wg_decide(const GreedyArgs& A, int m, uint8_t* fl
         return 0;
     }
 }
+// The same decision taken by ONE WAVE for one point: lane = candidate (lists longer than 64 in chunks), the two smallest
+// (distance, position) keys by wave reductions -- the sequential scan's `dist < bestDist` / `else if dist < bestDist2` keeps exactly
+// the first and second element in (distance, position) order.  Used for the points the claim rounds leave unresolved (many points
+// competing for the same features): they have to be visited in order anyway, but each visit costs ~60 wave-instructions instead
+// of a scalar walk over the list.
+__device__ __forceinline__ unsigned wg_wave_min(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+template <int MODE>
+__device__ __forceinline__ int wg_decide_wave(const GreedyArgs& A, int m, uint8_t* flag, int lane)
+{
+    const int c = A.cn[m];
+    const int* ci = A.ci + (long long)m * A.cap; const int* cd = A.cd + (long long)m * A.cap;
+    const int lvl = MODE == 1 ? A.qlevel[m] : 0;
+    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;                 // running best / second: dist << 16 | position
+    for (int base = 0; base < c; base += 64) {
+        const int k = base + lane;
+        unsigned key = 0xFFFFFFFFu;
+        if (k < c) {
+            const int idx = ci[k];
+            bool ok = !flag[idx];
+            if (MODE == 1) { const int kl = A.oct[idx]; ok = ok && !(kl < lvl - 1 || kl > lvl); }
+            if (ok) key = ((unsigned)cd[k] << 16) | (unsigned)k;
+        }
+        const unsigned b1 = wg_wave_min(key);
+        const unsigned b2 = wg_wave_min(key == b1 ? 0xFFFFFFFFu : key);      // keys are distinct (position), so this drops one lane
+        // merge {k1, k2} with {b1, b2}
+        const unsigned lo = k1 < b1 ? k1 : b1, hi = k1 < b1 ? b1 : k1;
+        const unsigned other = k1 < b1 ? k2 : b2;
+        k1 = lo; k2 = hi < other ? hi : other;
+    }
+    int result = 0;
+    if (lane == 0) {
+        const int bestDist = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16), bestDist2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 16);
+        if (MODE == 0) {
+            if (bestDist <= 100) {
+                const int bestIdx = ci[k1 & 0xFFFFu];
+                const int bestLevel = A.oct[bestIdx], bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : A.oct[ci[k2 & 0xFFFFu]];
+                if (!(bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2)) { A.out[bestIdx] = m; flag[bestIdx] = A.qflag[m]; result = 1; }
+            }
+        } else if (bestDist <= 50) {
+            const int bestIdx = ci[k1 & 0xFFFFu];
+            A.out[m] = bestIdx;
+            if (!A.qflag[m]) { flag[bestIdx] = 1; result = 1; }
+        }
+    }
+    return result;                                                // valid in lane 0
+}
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
 {
@@ -668,7 +719,15 @@ __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
         if (tid == 0) s_left = 0;
         __syncthreads();
         if (round >= WG_MAX_ROUNDS) {
-            if (tid == 0) { int cnt = 0; for (int m = 0; m < A.nq; m++) if (!resolved[m]) cnt += wg_decide<MODE>(A, m, flag); s_count += cnt; }
+            if (tid < 64) {                                        // wave 0 visits the rest in order
+                int cnt = 0;
+                for (int m = 0; m < A.nq; m++) {
+                    if (resolved[m]) continue;
+                    cnt += wg_decide_wave<MODE>(A, m, flag, tid);
+                    __builtin_amdgcn_wave_barrier();               // lane 0's flag write precedes the next point's reads (LDS, in order within the wave)
+                }
+                if (tid == 0) s_count += cnt;
+            }
             __syncthreads();
             break;
         }

@@ -15,7 +15,7 @@ from motioncheck_ccm_slam_amd.optimizer import Optimizer                # noqa: 
 from motioncheck_ccm_slam_amd.orb import ORBextractor                   # noqa: E402
 from motioncheck_ccm_slam_amd.vocabulary import ORBVocabulary, synthetic_tree  # noqa: E402
 from oracle import oracle_py as O                                       # noqa: E402  (checker / CPU baseline only)
-from sim3_problems import make_problem                                  # noqa: E402
+from sim3_problems import make_problem, make_pose_graph                 # noqa: E402
 
 
 def timed(fn, reps=5):
@@ -63,6 +63,52 @@ for i in range(2000):
 t_cpu = (time.perf_counter() - t0) * (nq / 2000)
 out["F1_window_candidates"] = {"queries": nq, "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms_scaled_from_2000": round(t_cpu * 1e3, 1),
                                "note": "CPU figure is the list only (no distances) through a Python loop"}
+
+# F1 with the acceptance on the device (round 2): 20,000 map points against one keyframe -- Fuse's selection (k_window_select) and
+# SearchByProjection(KF, Scw) with its order-dependent bookkeeping (k_window_greedy); one index per map point comes back
+nmp = 20000
+src = rng.integers(0, n, nmp)
+mp_desc = desc[src] ^ np.packbits(rng.random((nmp, 256)) < 0.05, axis=1, bitorder="little")
+px = (fr.kx[src] + rng.normal(0, 2.0, nmp)).astype("f4"); py = (fr.ky[src] + rng.normal(0, 2.0, nmp)).astype("f4")
+lvl = np.clip(fr.oct[src] + rng.integers(0, 2, nmp), 0, 7)
+valid = np.ones(nmp, np.uint8); observed = (rng.random(nmp) < 0.1).astype(np.uint8); matched = (rng.random(n) < 0.1).astype(np.uint8)
+is2 = ex.GetInverseScaleSigmaSquares()
+t_gpu = timed(lambda: m.FuseSelect(fr, sf, is2, valid, px, py, lvl, mp_desc, 3.0, True))
+t_cpu = timed(lambda: O.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, valid, px, py, lvl, mp_desc, 3.0, True), 2)
+out["F1_fuse_select_20k"] = {"map_points": nmp, "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms": round(t_cpu * 1e3, 1), "acceptance": "device (k_window_select)"}
+t_gpu = timed(lambda: m.SearchByProjectionSim3(fr, sf, valid, px, py, lvl, mp_desc, observed, matched, 8.0))
+t_cpu = timed(lambda: O.search_by_projection_sim3(fr, sf, valid, px, py, lvl, mp_desc, observed, matched, 8.0), 2)
+os.environ["CCM_WINDOW_HOST_ACCEPT"] = "1"      # read once per process by the library: the host-acceptance figure comes from a child process
+import subprocess
+child = subprocess.run([sys.executable, "-c", "import sys, json, time, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                        "from motioncheck_ccm_slam_amd import _lib, synth\nfrom motioncheck_ccm_slam_amd.matcher import FrameGridView, ORBmatcher\n"
+                        "from motioncheck_ccm_slam_amd.orb import ORBextractor\nctx = _lib.Context(0); ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)\n"
+                        "kps, desc = ex(synth.frame(0)); fr = FrameGridView(kps['x'], kps['y'], kps['octave'], desc); sf = ex.GetScaleFactors(); n = len(fr.kx)\n"
+                        "rng = np.random.default_rng(5); nmp = 20000; src = rng.integers(0, n, nmp)\n"
+                        "mp = desc[src] ^ np.packbits(rng.random((nmp, 256)) < 0.05, axis=1, bitorder='little')\n"
+                        "px = (fr.kx[src] + rng.normal(0, 2.0, nmp)).astype('f4'); py = (fr.ky[src] + rng.normal(0, 2.0, nmp)).astype('f4')\n"
+                        "lvl = np.clip(fr.oct[src] + rng.integers(0, 2, nmp), 0, 7); v = np.ones(nmp, np.uint8); ob = (rng.random(nmp) < 0.1).astype(np.uint8); mt = (rng.random(n) < 0.1).astype(np.uint8)\n"
+                        "m = ORBmatcher(0.8, ctx=ctx); m.SearchByProjectionSim3(fr, sf, v, px, py, lvl, mp, ob, mt, 8.0)\n"
+                        "t = time.perf_counter()\nfor _ in range(5): m.SearchByProjectionSim3(fr, sf, v, px, py, lvl, mp, ob, mt, 8.0)\n"
+                        "print((time.perf_counter() - t) / 5)" % (ROOT, os.path.join(ROOT, "tests"))],
+                       capture_output=True, text=True, env=dict(os.environ))
+del os.environ["CCM_WINDOW_HOST_ACCEPT"]
+t_host_accept = float(child.stdout.strip().splitlines()[-1]) if child.returncode == 0 else None
+out["F1_search_by_projection_sim3_20k"] = {"map_points": nmp, "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms": round(t_cpu * 1e3, 1),
+                                           "acceptance": "device (k_window_greedy)",
+                                           "round1_path_lists_to_host_ms": round(t_host_accept * 1e3, 3) if t_host_accept else child.stderr[-300:]}
+
+# F4: essential graph at BASELINE's map size, block-sparse Cholesky on the device (round 2; round 1: dense 13,993^2 + rocSOLVER)
+g_rng = np.random.default_rng(9)
+sim3, fixed, ei, ej, meas, truth = make_pose_graph(O, g_rng, n=2000, drift=0.002, scale_drift=0.0005, covis=3)
+res = {}
+def run_ess():
+    res["out"] = Optimizer.OptimizeEssentialGraph(sim3, fixed, ei, ej, meas, False, 20, ctx=ctx)
+t_gpu = timed(run_ess, 3)
+info = res["out"][1]
+out["F4_essential_graph_2000"] = {"keyframes": 2000, "edges": int(len(ei)), "gpu_ms": round(t_gpu * 1e3, 2), "iterations": info["iterations_done"],
+                                  "factor_blocks": info["factor_blocks"], "factor_rounds": info["factor_rounds"], "solver_MB": round(info["solver_bytes"] / 1e6, 2),
+                                  "cpu_oracle": "not run (dense CPU Cholesky of 13,993^2: minutes)"}
 
 # F2: pose-only optimisation, 256 frames x 300 correspondences
 F, per = 256, 300

@@ -573,7 +573,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                         const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
                         static const double env_tol = getenv("CCM_PCG_TOL") ? atof(getenv("CCM_PCG_TOL")) : 0.0;
-                        const double pcg_tol = env_tol > 0 ? env_tol : (opt->pcg_tol > 0 ? opt->pcg_tol : 1e-8);   // relative residual
+                        const double pcg_tol = env_tol > 0 ? env_tol : (opt->pcg_tol > 0 ? opt->pcg_tol : 1e-6);   // relative residual (default: see ccm_hot.h)
                         const double tol2 = pcg_tol * pcg_tol;
                         volatile double* sc = S.pinned;
                         int itc = 0, badh = 0, last_len = 0;

@@ -271,9 +271,10 @@ int ccm_match_bow(ccm_ctx* c, const ccm_bow_options* o, const uint8_t* desc1, co
 // F1: windowed matching.  The GPU enumerates, for every query, the features inside its
 // search window with their Hamming distances (k_window_candidates).  The acceptance runs on the device too for the matchers
 // a server batches over many map points: Fuse / SearchBySim3 (k_window_select: no coupling between queries), and
-// SearchByProjection(Frame, map points) / SearchByProjection(KF, Scw) (k_window_greedy: the reference's order-dependent
-// occupancy bookkeeping resolved by claim rounds, bit-identical to the sequential loop).  The frame-to-frame and the
-// initialisation matcher (rotation histograms over all accepted matches) keep their acceptance loops on the host.
+// SearchByProjection(Frame, map points) / SearchByProjection(KF, Scw) / SearchByProjection(Frame, Frame | KeyFrame)
+// (k_window_greedy: the reference's order-dependent occupancy bookkeeping resolved by claim rounds, bit-identical to the
+// sequential loop; the frame matcher's rotation histogram and its three maxima in the same kernel).  Only the
+// initialisation matcher (called once per map) keeps its acceptance loop on the host.
 struct WinGrid {
     int n, cols, rows; float min_x, min_y, inv_w, inv_h;
     const float* kx; const float* ky; const int* oct; const uint8_t* desc; const int* cell_first; const int* cell_items;
@@ -286,11 +287,12 @@ void match_launch_window_select(hipStream_t, const WinGrid&, int nq, const float
 struct GreedyArgs {
     int nq, n, cap; const int* ci; const int* cd; const int* cn; const uint8_t* active; const int* qlevel; const int* oct; const uint8_t* qflag;
     uint8_t* flag; float nnratio; int* out; int* status;
+    int orb_dist, check_ori; const float* q_angle; const float* f_angle; int* ev;
 };
 size_t match_window_greedy_lds(int n, int nq);
 int match_launch_window_greedy(hipStream_t, int mode, const GreedyArgs&);
 
-struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn, sel_i, sel_d, is2, act, qlvl, qflag, flag, out, status; };
+struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn, sel_i, sel_d, is2, act, qlvl, qflag, flag, out, status, qang, fang, ev; };
 // LDS the single-workgroup acceptance kernel may ask for (claim + flag per feature, one byte per query); larger problems take the
 // host loops below
 static const size_t kGreedyLdsMax = 150 * 1024;
@@ -363,7 +365,8 @@ static int window_candidates(ccm_ctx* c, const ccm_frame_grid* f, int nq, const 
 // or < 0 on error.  Lists longer than `cap` make the kernel report the needed length and the call repeats once.
 static int window_greedy(ccm_ctx* c, const ccm_frame_grid* f, int nq, const float* qx, const float* qy, const float* qr,
                          const int32_t* minl, const int32_t* maxl, const uint8_t* qdesc, int mode, const uint8_t* active, const int32_t* qlevel,
-                         const uint8_t* qflag, uint8_t* flag, float nnratio, int32_t* out, int n_out)
+                         const uint8_t* qflag, uint8_t* flag, float nnratio, int32_t* out, int n_out,
+                         int orb_dist = 0, int check_ori = 0, const float* q_angle = nullptr, const float* f_angle = nullptr)
 {
     std::vector<int32_t> d0, d1, d2;
     int cap = 64;
@@ -379,10 +382,15 @@ static int window_greedy(ccm_ctx* c, const ccm_frame_grid* f, int nq, const floa
         };
         if ((rc = up(W.act, active, (size_t)nq)) || (rc = up(W.qflag, qflag, (size_t)nq)) || (rc = up(W.flag, flag, (size_t)f->n))) return rc;
         if (qlevel && (rc = up(W.qlvl, qlevel, (size_t)nq * 4))) return rc;
+        if (mode == 2) {
+            CCM_RESERVE(c, W.ev, std::max<size_t>((size_t)nq * 4, 16));
+            if (check_ori && ((rc = up(W.qang, q_angle, (size_t)nq * 4)) || (rc = up(W.fang, f_angle, (size_t)f->n * 4)))) return rc;
+        }
         CCM_RESERVE(c, W.out, std::max<size_t>((size_t)n_out * 4, 16)); CCM_RESERVE(c, W.status, 16);
         CCM_HIP(c, hipMemsetAsync(W.out.p, 0xFF, (size_t)n_out * 4, st));
         GreedyArgs A{ nq, f->n, cap, W.ci.as<int>(), W.cd.as<int>(), W.cn.as<int>(), W.act.as<uint8_t>(), qlevel ? W.qlvl.as<int>() : nullptr,
-                      W.oct.as<int>(), W.qflag.as<uint8_t>(), W.flag.as<uint8_t>(), nnratio, W.out.as<int>(), W.status.as<int>() };
+                      W.oct.as<int>(), W.qflag.as<uint8_t>(), W.flag.as<uint8_t>(), nnratio, W.out.as<int>(), W.status.as<int>(),
+                      orb_dist, check_ori, W.qang.as<float>(), W.fang.as<float>(), W.ev.as<int>() };
         if (match_launch_window_greedy(st, mode, A)) return ccm_fail(c, CCM_E_DEVICE, "k_window_greedy: LDS request refused");
         CCM_HIP(c, hipGetLastError());
         int status[3] = { 0, 0, 0 };
@@ -401,7 +409,7 @@ void match_window_free(WindowBufs* w)
 {
     if (!w) return;
     DevBuf* all[] = { &w->kx, &w->ky, &w->oct, &w->desc, &w->cfirst, &w->citems, &w->qx, &w->qy, &w->qr, &w->minl, &w->maxl, &w->qdesc, &w->ci, &w->cd, &w->cn,
-                      &w->sel_i, &w->sel_d, &w->is2, &w->act, &w->qlvl, &w->qflag, &w->flag, &w->out, &w->status };
+                      &w->sel_i, &w->sel_d, &w->is2, &w->act, &w->qlvl, &w->qflag, &w->flag, &w->out, &w->status, &w->qang, &w->fang, &w->ev };
     for (DevBuf* b : all) b->release();
     delete w;
 }
@@ -502,6 +510,10 @@ int ccm_search_by_projection_frame(ccm_ctx* c, const ccm_frame_grid* f, const fl
         qr[i] = th * scale_factors[last_octave[i]];                           // :1401
         minl[i] = last_octave[i] - 1; maxl[i] = last_octave[i] + 1;           // :1405
     }
+    static const bool host_accept = getenv("CCM_WINDOW_HOST_ACCEPT") && atoi(getenv("CCM_WINDOW_HOST_ACCEPT")) != 0;   // test switch
+    if (!host_accept && match_window_greedy_lds(f->n, n_last) <= kGreedyLdsMax)
+        return window_greedy(c, f, n_last, u, v, qr.data(), minl.data(), maxl.data(), mp_desc, 2, valid, nullptr, mp_has_obs, occupied, 0.f, match, f->n,
+                             orb_dist, check_ori, last_angle, cur_angle);
     int cap = 64;
     std::vector<int32_t> ci, cd, cn;
     for (;;) {

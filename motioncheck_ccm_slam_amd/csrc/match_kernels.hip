@@ -602,8 +602,11 @@ struct GreedyArgs {
     const uint8_t* qflag;                             // Observations() > 0  /  already observed in the keyframe
     uint8_t* flag;                                    // in/out per feature: occupied / matched
     float nnratio;
-    int* out;                                         // MODE 0: match[feature] = point; MODE 1: best_idx[point] = feature
+    int* out;                                         // MODE 0 / 2: match[feature] = point; MODE 1: best_idx[point] = feature
     int* status;                                      // [0] matches (or -1: a list overflowed), [1] longest list, [2] rounds
+    // MODE 2 (SearchByProjection(CurrentFrame, LastFrame / KeyFrame), ORBmatcher.cpp:1350-1476, :1478-1605): acceptance threshold,
+    // rotation check and its inputs; ev[point] = accepted feature << 8 | rotation bin (or -1)
+    int orb_dist, check_ori; const float* q_angle; const float* f_angle; int* ev;
 };
 #define WG_MAX_ROUNDS 48
 template <int MODE>
@@ -624,6 +627,29 @@ __device__ __forceinline__ int wg_decide(const GreedyArgs& A, int m, uint8_t* fl
             if (bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2) return 0;
             A.out[bestIdx] = m;
             flag[bestIdx] = A.qflag[m];
+            return 1;
+        }
+        return 0;
+    } else if (MODE == 2) {
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < c; k++) {
+            const int idx = ci[k];
+            if (flag[idx]) continue;                                            // :1419-1421
+            const int dist = cd[k];
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        A.ev[m] = -1;
+        if (bestDist <= A.orb_dist) {                                           // TH_HIGH (:1432) / ORBdist (:1556)
+            A.out[bestIdx] = m;
+            flag[bestIdx] = A.qflag[m];
+            int bin = 255;
+            if (A.check_ori) {                                                  // :1437-1447
+                float rot = A.q_angle[m] - A.f_angle[bestIdx];
+                if (rot < 0.0) rot += 360.0f;
+                bin = (int)roundf(rot * (1.0f / 30));
+                if (bin == 30) bin = 0;
+            }
+            A.ev[m] = (bestIdx << 8) | bin;
             return 1;
         }
         return 0;
@@ -659,6 +685,7 @@ __device__ __forceinline__ unsigned wg_wave_min(unsigned v)
 template <int MODE>
 __device__ __forceinline__ int wg_decide_wave(const GreedyArgs& A, int m, uint8_t* flag, int lane)
 {
+    if (MODE == 2) { int r = 0; if (lane == 0) r = wg_decide<2>(A, m, flag); return r; }      // in-order pass of the frame matcher: one lane
     const int c = A.cn[m];
     const int* ci = A.ci + (long long)m * A.cap; const int* cd = A.cd + (long long)m * A.cap;
     const int lvl = MODE == 1 ? A.qlevel[m] : 0;
@@ -751,6 +778,40 @@ __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
         if (s_left == 0) break;
         __syncthreads();                                             // everybody has read s_left before it is reset
     }
+    if (MODE == 2 && A.check_ori) {
+        // rotation consistency (:1453-1471): histogram of the accepted matches' angle differences, the three largest bins stay
+        // (ComputeThreeMaxima :1607-1648), every match recorded in another bin is cleared -- also when a later point re-took the feature
+        __shared__ int hist[30], keep3[3], s_removed;
+        if (tid < 30) hist[tid] = 0;
+        if (tid == 0) s_removed = 0;
+        __syncthreads();
+        for (int m = tid; m < A.nq; m += 1024) { const int e = (A.active[m] && A.cn[m] > 0) ? A.ev[m] : -1; if (e >= 0) atomicAdd(&hist[e & 255], 1); }
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < 30; i++) {
+                const int sz = hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; i3 = i2; i2 = i1; i1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; i3 = i2; i2 = i; }
+                else if (sz > max3) { max3 = sz; i3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { i3 = -1; }
+            keep3[0] = i1; keep3[1] = i2; keep3[2] = i3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int m = tid; m < A.nq; m += 1024) {
+            const int e = (A.active[m] && A.cn[m] > 0) ? A.ev[m] : -1;
+            if (e < 0) continue;
+            const int b = e & 255;
+            if (b != keep3[0] && b != keep3[1] && b != keep3[2]) { A.out[e >> 8] = -1; removed++; }
+        }
+        if (removed) atomicAdd(&s_removed, removed);
+        __syncthreads();
+        if (tid == 0) s_count -= s_removed;
+        __syncthreads();
+    }
     for (int i = tid; i < A.n; i += 1024) A.flag[i] = flag[i];
     if (tid == 0) { A.status[0] = s_count; A.status[1] = s_maxcn; A.status[2] = round; }
 }
@@ -761,9 +822,12 @@ int match_launch_window_greedy(hipStream_t s, int mode, const GreedyArgs& A)
     if (mode == 0) {
         if (hipFuncSetAttribute((const void*)k_window_greedy<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_window_greedy<0>, dim3(1), dim3(1024), lds, s, A);
-    } else {
+    } else if (mode == 1) {
         if (hipFuncSetAttribute((const void*)k_window_greedy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_window_greedy<1>, dim3(1), dim3(1024), lds, s, A);
+    } else {
+        if (hipFuncSetAttribute((const void*)k_window_greedy<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_window_greedy<2>, dim3(1), dim3(1024), lds, s, A);
     }
     return 0;
 }

@@ -283,3 +283,15 @@ def test_device_acceptance_chains_and_large_batches(ctx, oracle):
     bi, bd = m.FuseSelect(fr, sf, is2, valid, px, py, level, mp_desc, 3.0, True)
     rbi, rbd = oracle.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, valid, px, py, level, mp_desc, 3.0, True)
     assert (bi == rbi).all() and (bd == rbd).all() and (bi >= 0).sum() > 5000
+
+
+def test_host_acceptance_paths_stay_exact():
+    """The acceptance loops on the host (the round-1 path, still used when a problem exceeds the single workgroup's LDS) stay covered:
+    a child process with CCM_WINDOW_HOST_ACCEPT=1 reruns the matcher tests of this file against the oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CCM_WINDOW_HOST_ACCEPT="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "search_by_projection or frame_to_frame or keyframe_overload or sim3 or device_acceptance"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]

@@ -363,6 +363,20 @@ def main():
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(spmv_bytes / per_it / 1e9 / HBM_PEAK_GBS, 5),
                                  "note": "whole PCG iteration (three kernels + host round trips) charged to the mat-vec's bytes"}
             gba["roofline"] = roof
+            if solo:
+                # BASELINE config 4 beside it: the local BA Mapping runs per keyframe (20 free + 10 fixed keyframes, 5000 points, 5 robust + 10
+                # plain iterations with outlier relabelling, src/Optimizer.cpp:536-568) -- a latency figure, host buffers in and out
+                gl = synth.local_ba_graph()
+                Optimizer.LocalBundleAdjustmentClient(gl, ctx=ctx)
+                tl = []
+                for _ in range(5):
+                    t1 = time.perf_counter(); rl = Optimizer.LocalBundleAdjustmentClient(gl, ctx=ctx); tl.append(time.perf_counter() - t1)
+                lb = {"workload": "configs[3]: 20 free + 10 fixed keyframes, 5000 points, %d edges, 5 + 10 LM iterations" % len(gl["edge_pose"]),
+                      "ms_per_call": round(float(np.median(tl)) * 1e3, 3), "iterations": rl["iterations_done"], "outliers": int(rl["outlier"].sum())}
+                if not args.no_cpu:
+                    from oracle import oracle_py as O
+                    t1 = time.perf_counter(); O.ba_solve(gl, 5, float(np.sqrt(5.991)), 10); lb["cpu_oracle_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
+                gba["local_ba"] = lb
             if solo and not args.no_cpu:
                 from oracle import oracle_py as O
                 tc = time.perf_counter()

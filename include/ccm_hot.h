@@ -345,7 +345,9 @@ typedef struct {
     double chi2_final;        /* activeRobustChi2 at the last accepted state */
     double lambda_final;
     int    stopped;           /* 1 if stop_flag ended the solve */
-    /* per-stage wall seconds, mirroring G2OBatchStatistics (core/batch_stats.h) */
+    /* per-stage wall seconds, mirroring G2OBatchStatistics (core/batch_stats.h).  They always add up to the LM loop's wall time;
+     * below 200,000 edges the stream is not synchronised at every phase boundary (that cost a quarter of a local BA), so a phase's
+     * GPU time is booked where the next necessary synchronisation falls (CCM_BA_TIMERS=1 forces exact phases). */
     double t_linearize, t_schur, t_solve, t_update;
     uint8_t* edge_outlier;    /* optional out [n_edges]: chi2 > outlier_chi2 || depth <= 0 at the end (:582) */
     /* structure of the reduced camera system and work of its solver */

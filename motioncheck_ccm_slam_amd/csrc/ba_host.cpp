@@ -48,6 +48,8 @@ void sp_launch_schur_blocks(hipStream_t, const BaDev&, const double* Y, const un
 void sp_launch_bschur(hipStream_t, const BaDev&, const double* db, double* bs);
 void sp_launch_add_lambda(hipStream_t, const int* diag, int nfree, double lambda, double* Hb);
 void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs);
+int dense_small_max();
+int dense_launch_small_solve(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int n, const double* b, double* x, int* bad);
 size_t pcg_minv_bytes(int nfree);
 hipError_t pcg_launch_minv(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int nfree, double* Minv, int* bad);
 void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C);
@@ -249,6 +251,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         perm.swap(out);
     }
     const int E = (int)perm.size();
+    // Per-phase timers need a stream synchronisation at every phase boundary.  On a large graph that costs nothing next to the phases; on a
+    // local BA (tens of keyframes, launch-bound) the four extra round trips per LM trial were a quarter of the call, so small problems
+    // skip them: their timers still add up to the wall time, but a phase's GPU time is booked where the next necessary sync happens.
+    static const bool force_timers = getenv("CCM_BA_TIMERS") && atoi(getenv("CCM_BA_TIMERS")) != 0;
+    const bool fine_timers = force_timers || E >= 200000;
     // a sorted, unsharded edge list is used where it lies (no staging copies: another 5 ms at config 5)
     const bool direct = sorted && E == Eall && l0 == 0;
     std::vector<int> e_pose_v, e_pt_v, pt_first(L + 1, 0);
@@ -511,7 +518,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 for (double v : dg) md = std::max(md, std::fabs(v));
                 lambda = 1e-5 * md; ni = 2; nBad = 0;
             }
-            CCM_HIP(c, hipStreamSynchronize(st));
+            if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
             lin_.end();
             res->t_linearize += secs(t0, clk::now());
             double rho = 0;
@@ -531,7 +538,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     { ProfScope ps(c, CCM_PROF_BA_BSCHUR); sp_launch_bschur(st, D, S.db.as<double>(), D.bs); }
                     if ((rc = comm_allreduce_f64(c, Hb, 36 * (size_t)nb + (size_t)n, false))) return rc;
                     sp_launch_add_lambda(st, S.diag_id.as<int>(), nfree, lambda, Hb);
-                    CCM_HIP(c, hipStreamSynchronize(st));
+                    if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
                     t2 = clk::now();
                     res->t_schur += secs(t1, t2);
                     bool solved = false;
@@ -615,19 +622,26 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     }
                     if (!solved) {
                         // dense solve by the in-house block Gauss-Jordan (see dense_launch_solve for why not rocSOLVER)
+                        static const bool no_small = getenv("CCM_BA_NO_SMALL_SOLVE") && atoi(getenv("CCM_BA_NO_SMALL_SOLVE")) != 0;   // test switch
+                        CCM_HIP(c, hipMemsetAsync(info_dev, 0, 4, st));
+                        if (!no_small && n <= dense_small_max()) {
+                            // a local BA's system: factored and solved by one workgroup in LDS, one launch (see k_dense_small_solve)
+                            if (dense_launch_small_solve(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, (int)n, D.bs, D.x, info_dev))
+                                return ccm_fail(c, CCM_E_DEVICE, "k_dense_small_solve: LDS request refused");
+                        } else {
                         const size_t npd = (size_t)dense_pitch(n);
                         CCM_RESERVE(c, S.Hs, (npd * npd + 48 * 48 + 8) * 8);
                         double* Hs = S.Hs.as<double>();
                         CCM_HIP(c, hipMemsetAsync(Hs, 0, npd * npd * 8, st));
-                        CCM_HIP(c, hipMemsetAsync(info_dev, 0, 4, st));
                         sp_launch_to_dense(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, (long long)npd, Hs);   // row-major upper block triangle, pitch npd
                         dense_launch_solve(st, Hs, (int)n, (int)npd, D.bs, D.x, info_dev);
+                        }
                         int info = 0;
                         CCM_HIP(c, hipMemcpyAsync(&info, info_dev, 4, hipMemcpyDeviceToHost, st));
                         CCM_HIP(c, hipStreamSynchronize(st));
                         ok2 = info == 0;
                     }
-                    CCM_HIP(c, hipStreamSynchronize(st));
+                    if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
                 } else {
                     // no free keyframe: only the landmark inverse is needed for the back-substitution
                     sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>());
@@ -672,7 +686,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     if (L) CCM_HIP(c, hipMemcpyAsync(D.points, S.save_points.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
                 }
                 qmax++;
-                CCM_HIP(c, hipStreamSynchronize(st));
+                if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
                 res->t_update += secs(t3, clk::now());
             } while (rho < 0 && qmax < 10 && !stop_requested());
             res->iterations_done++;

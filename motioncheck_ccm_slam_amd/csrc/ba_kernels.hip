@@ -6,7 +6,7 @@
 //   k_ba_pose_rt      quaternion+t -> R|t per pose
 //   k_ba_errors       computeActiveErrors + activeRobustChi2            (sparse_optimizer.cpp:61-114)
 //   k_ba_lin_landmark linearizeOplus + constructQuadraticForm, landmark side: Hll, b_l, Hpl per edge
-//   k_ba_lin_pose     the same, pose side: Hpp, b_p (one wave per free pose, fixed summation order)
+//   k_ba_lin_pose     the same, pose side: Hpp, b_p (one workgroup per free pose, fixed summation order)
 //   (Schur complement and reduced solve: ba_sparse.hip)
 //   k_ba_backsub      x_l = Dinv (b_l - Hpl^T x_p)                        (block_solver.hpp:461-481)
 //   k_ba_update       oplus on poses (exp map) and points                 (sparse_optimizer.cpp:422-435)
@@ -101,8 +101,59 @@ __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_d
     for (int i = 0; i < 3; i++) D.bl[3 * (long long)l + i] = b[i];
 }
 
-// One wave per free pose: lanes stride the pose's edge list, then a fixed butterfly reduction.
+// One workgroup (4 waves) per free pose: the waves take every fourth 64-edge run of the pose's list, reduce inside the wave by a fixed
+// butterfly and are added wave 0..3 by wave 0.  (One WAVE per pose, as in round 1, left a 20-keyframe local BA with 20 waves on a chip
+// with room for 8192, and config 5 with 2000: 56 us resp. 65 us per call.)
 __global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D, double huber_delta)
+{
+    __shared__ double part[4][28];
+    const int f = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (f >= D.nfree) return;
+    const int pi = D.pose_of_free[f];
+    double Rt[12], K[4];
+    for (int i = 0; i < 12; i++) Rt[i] = D.Rt[12 * (long long)pi + i];
+    for (int i = 0; i < 4; i++) K[i] = D.intr[4 * (long long)pi + i];
+    double H[21], b[6];
+    for (int i = 0; i < 21; i++) H[i] = 0;
+    for (int i = 0; i < 6; i++) b[i] = 0;
+    for (int k = D.pose_first[f] + threadIdx.x; k < D.pose_first[f + 1]; k += 256) {
+        const int e = D.pose_edges[k];
+        if (!D.active[e]) continue;
+        double er[2], A[6], B[12];
+        ba_edge_eval(Rt, K, D.points + 3 * (long long)D.edge_point[e], D.obs + 2 * (long long)e, er, A, B, nullptr);
+        const double om = D.info[e];
+        double r0, r1 = 1.;
+        if (huber_delta > 0) ba_huber(om * (er[0] * er[0] + er[1] * er[1]), huber_delta, &r0, &r1);
+        const double w = r1 * om;
+        const double g0 = -om * er[0] * r1, g1 = -om * er[1] * r1;
+        int m = 0;
+        for (int i = 0; i < 6; i++) {
+            b[i] += B[i] * g0 + B[6 + i] * g1;
+            for (int j = i; j < 6; j++) H[m++] += w * (B[i] * B[j] + B[6 + i] * B[6 + j]);
+        }
+    }
+    for (int i = 0; i < 21; i++) H[i] = wave_sum_d(H[i]);
+    for (int i = 0; i < 6; i++) b[i] = wave_sum_d(b[i]);
+    if (lane == 0) {
+        for (int i = 0; i < 21; i++) part[wv][i] = H[i];
+        for (int i = 0; i < 6; i++) part[wv][21 + i] = b[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const double v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        if (threadIdx.x >= 21) D.bp[6 * (long long)f + (threadIdx.x - 21)] = v;
+        else {
+            int i = 0, m = threadIdx.x;                       // packed upper-triangle index -> (i, j)
+            while (m >= 6 - i) { m -= 6 - i; i++; }
+            const int j = i + m;
+            double* o = D.Hpp + 36 * (long long)f;
+            o[i * 6 + j] = v; o[j * 6 + i] = v;
+        }
+    }
+}
+
+// One wave per free pose: lanes stride the pose's edge list, then a fixed butterfly reduction.
+__global__ __launch_bounds__(256) void k_ba_lin_pose_wave(BaDev D, double huber_delta)
 {
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f >= D.nfree) return;
@@ -229,7 +280,10 @@ void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial,
 void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
 {
     if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
-    if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
+    // few keyframes with long edge lists (local BA): a workgroup per keyframe; maps with thousands of keyframes: a wave each (measured:
+    // the workgroup form costs config 5 another 60 us per linearisation, the wave form costs config 4 40 us)
+    if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nfree), dim3(256), 0, s, D, hd);
+    else if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
 }
 void ba_launch_backsub(hipStream_t s, const BaDev& D) { if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub, dim3(nblk(D.L, 256)), dim3(256), 0, s, D); }
 void ba_launch_update(hipStream_t s, const BaDev& D)

@@ -163,12 +163,13 @@ __global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double* __restrict__
 // cost two dependent memory round trips).  The accumulation order -- the hardware's k order inside a wave, wave 0..3 at the
 // end -- is fixed: reproducible run to run.
 typedef double sp_v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                                                          const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb,
                                                          double* __restrict__ Hb)
 {
-    __shared__ double part[4][36];
+    __shared__ double part[NWV][36];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x;
     const int i = lane & 15, kq = lane >> 4;                // operand row (< 6 used), k within an MFMA
@@ -195,11 +196,11 @@ __global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* 
     };
     unsigned long long pr_next[3], pr_far[3];
     double av[3], bv[3], av_next[3], bv_next[3];
-    int p = p0 + 4 * wv;                                    // this wave's steps: 4 pairs each, 16 pairs apart
-    ld_idx(p, pr_next); ld_ops(pr_next, av, bv); ld_idx(p + 16, pr_next);
-    for (; p < p1; p += 16) {
+    int p = p0 + 4 * wv;                                    // this wave's steps: 4 pairs each, 4 NWV pairs apart
+    ld_idx(p, pr_next); ld_ops(pr_next, av, bv); ld_idx(p + 4 * NWV, pr_next);
+    for (; p < p1; p += 4 * NWV) {
         ld_ops(pr_next, av_next, bv_next);
-        ld_idx(p + 32, pr_far);
+        ld_idx(p + 8 * NWV, pr_far);
 #pragma unroll
         for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[m], acc, 0, 0, 0);
 #pragma unroll
@@ -218,12 +219,36 @@ __global__ __launch_bounds__(256) void k_sp_schur_blocks(BaDev D, const double* 
     if (threadIdx.x < 36) {
         const int rb = blk_row[b], cb = blk_col[b];
         const double base = rb == cb ? D.Hpp[36 * (long long)rb + threadIdx.x] : 0.0;
-        Hb[36 * (long long)b + threadIdx.x] = base - (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
+        double tot = part[0][threadIdx.x];
+#pragma unroll
+        for (int w2 = 1; w2 < NWV; w2++) tot += part[w2][threadIdx.x];                                  // wave 0 .. NWV-1: fixed order
+        Hb[36 * (long long)b + threadIdx.x] = base - tot;
     }
 }
 
-// one wave per free pose: bs = bp - sum over its edges of Hpl_e db(l_e), fixed order
+// one workgroup (4 waves) per free pose: bs = bp - sum over its edges of Hpl_e db(l_e); wave partials added 0..3 (fixed order)
 __global__ __launch_bounds__(256) void k_sp_bschur(BaDev D, const double* __restrict__ db, double* __restrict__ bs)
+{
+    __shared__ double part[4][6];
+    const int f = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (f >= D.nfree) return;
+    double c[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int k = D.pose_first[f] + threadIdx.x; k < D.pose_first[f + 1]; k += 256) {
+        const int e = D.pose_edges[k];
+        if (!D.active[e]) continue;
+        const double* B = D.Hpl + 18 * (long long)e;
+        const double* d = db + 3 * (long long)D.edge_point[e];
+        for (int i = 0; i < 6; i++) c[i] += B[i * 3] * d[0] + B[i * 3 + 1] * d[1] + B[i * 3 + 2] * d[2];
+    }
+    for (int i = 0; i < 6; i++)
+        for (int s = 32; s >= 1; s >>= 1) c[i] += __shfl_xor(c[i], s, 64);
+    if (lane == 0) for (int i = 0; i < 6; i++) part[wv][i] = c[i];
+    __syncthreads();
+    if (threadIdx.x < 6) bs[6 * (long long)f + threadIdx.x] = D.bp[6 * (long long)f + threadIdx.x] - (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
+}
+
+// one wave per free pose: bs = bp - sum over its edges of Hpl_e db(l_e), fixed order
+__global__ __launch_bounds__(256) void k_sp_bschur_wave(BaDev D, const double* __restrict__ db, double* __restrict__ bs)
 {
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f >= D.nfree) return;
@@ -837,9 +862,17 @@ void sp_launch_dinv(hipStream_t s, const BaDev& D, double lambda, double* Y, dou
 }
 void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, const unsigned long long* pairs, const int* st, const int* en,
                             const int* br, const int* bc, int nb, double* Hb)
-{ if (nb > 0) hipLaunchKernelGGL(k_sp_schur_blocks, dim3(nb), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb); }
+{
+    // few blocks with long pair lists (a local BA: 210 blocks of ~1000 pairs) get 16 waves per block, maps with many blocks 4
+    if (nb <= 0) return;
+    if (nb < 2048) hipLaunchKernelGGL(k_sp_schur_blocks<16>, dim3(nb), dim3(1024), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
+    else hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3(nb), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
+}
 void sp_launch_bschur(hipStream_t s, const BaDev& D, const double* db, double* bs)
-{ if (D.nfree > 0) hipLaunchKernelGGL(k_sp_bschur, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, db, bs); }
+{
+    if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_sp_bschur, dim3(D.nfree), dim3(256), 0, s, D, db, bs);
+    else if (D.nfree > 0) hipLaunchKernelGGL(k_sp_bschur_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, db, bs);
+}
 void sp_launch_add_lambda(hipStream_t s, const int* diag, int nfree, double lambda, double* Hb)
 { hipLaunchKernelGGL(k_sp_add_lambda, dim3(nblk(6LL * nfree, 256)), dim3(256), 0, s, diag, nfree, lambda, Hb); }
 void sp_launch_to_dense(hipStream_t s, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs)
@@ -897,6 +930,193 @@ void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const 
 void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc, const PcgCoarse& C)
 {
     hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nblk(6LL * nfree, PCG_UPD_TPB), part, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
+}
+
+// Reduced systems of a local BA (config 4: 20 free keyframes, n = 120 unknowns) are solved by ONE workgroup inside LDS: the upper
+// blocks are scattered into a dense lower triangle, factored L L^T column by column (two barriers per column), and the two
+// triangular solves follow in the same launch.  The block Gauss-Jordan path below needs ~14 launches for such a system and took
+// 0.5 ms per LM trial -- 70 % of the whole local BA; this takes one.  n <= DENSE_SMALL_MAX so that n^2 + n doubles fit the CU's LDS.
+#define DENSE_SMALL_MAX 138
+#define DS_TPB 320
+// Every 6x6 tile of the lower triangle lives in the REGISTERS of one thread for the whole factorisation (n <= 138: at most 276 tiles):
+// per block column the diagonal tile's owner factors it and publishes it in LDS, the owners of the tiles below solve against it and
+// publish the panel, every remaining tile subtracts panel_I panel_K^T from its registers -- two barriers per block column, and the only
+// LDS traffic is the panel.  (The same algorithm with the matrix in LDS took 133 us at n = 120, column by column 256 us.)
+__global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __restrict__ Hb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                              int nb, int n, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ bad)
+{
+    extern __shared__ double ds_lds[];
+    double* A = ds_lds;                      // [n][n]: the factor for the triangular solves (lower triangle)
+    double* v = ds_lds + (size_t)n * n;      // [n] right-hand side / solution
+    __shared__ double s_ljj[36];
+    __shared__ double s_panel[DENSE_SMALL_MAX / 6][36];
+    __shared__ int s_tile_blk[DENSE_SMALL_MAX / 6 * (DENSE_SMALL_MAX / 6 + 1) / 2];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    const int nbk = n / 6, ntiles = nbk * (nbk + 1) / 2;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < ntiles; i += DS_TPB) s_tile_blk[i] = -1;
+    for (int i = tid; i < n; i += DS_TPB) v[i] = b[i];
+    __syncthreads();
+    for (int k = tid; k < nb; k += DS_TPB) { const int r = blk_row[k], c = blk_col[k]; if (r <= c && c < nbk) s_tile_blk[c * (c + 1) / 2 + r] = k; }
+    __syncthreads();
+    // tile (I, K), K <= I, of thread tid
+    int I = 0, K = 0;
+    const bool have = tid < ntiles;
+    if (have) { while ((I + 1) * (I + 2) / 2 <= tid) I++; K = tid - I * (I + 1) / 2; }
+    double T[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) T[i][k] = 0.0;
+    if (have && s_tile_blk[tid] >= 0) {
+        const double* B = Hb + 36LL * s_tile_blk[tid];                       // stored block (row K, col I): tile(i, k) = B[k][i]
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) T[i][k] = B[k * 6 + i];
+        if (I == K) {                                                        // a diagonal block is stored whole; keep it exactly symmetric (upper half wins)
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k < i; k++) T[i][k] = T[k][i];
+        }
+    }
+    for (int J = 0; J < nbk; J++) {
+        if (have && I == J && K == J) {                                      // 6x6 Cholesky of the diagonal tile
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double d = T[c][c];
+#pragma unroll
+                for (int k = 0; k < c; k++) d -= T[c][k] * T[c][k];
+                if (!(d > 0.0)) { s_bad = 1; d = 1.0; }
+                d = sqrt(d); T[c][c] = d;
+                const double id = 1.0 / d;
+#pragma unroll
+                for (int r = c + 1; r < 6; r++) {
+                    double w = T[r][c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) w -= T[r][k] * T[c][k];
+                    T[r][c] = w * id;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) { if (k > i) T[i][k] = 0.0; s_ljj[i * 6 + k] = T[i][k]; }
+        }
+        __syncthreads();
+        if (have && K == J && I > J) {                                       // panel tile: X L_JJ^T = T, row by row
+            double lj[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k <= i; k++) lj[i][k] = s_ljj[i * 6 + k];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double w = T[r][c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) w -= T[r][k] * lj[c][k];
+                    T[r][c] = w / lj[c][c];
+                }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) s_panel[I][i * 6 + k] = T[i][k];
+        }
+        __syncthreads();
+        if (have && K > J) {                                                 // trailing tile: T -= panel_I panel_K^T
+            double pi[6][6], pk[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) { pi[i][k] = s_panel[I][i * 6 + k]; pk[i][k] = s_panel[K][i * 6 + k]; }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    double w = 0;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) w += pi[i][q] * pk[k][q];
+                    T[i][k] -= w;
+                }
+        }
+    }
+    if (have) {                                                              // the factor to LDS for the two triangular solves
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) A[(6 * I + i) * n + 6 * K + k] = T[i][k];
+    }
+    __syncthreads();
+    for (int J = 0; J < nbk; J++) {                                          // L y = b, block column by block column
+        const int j0 = 6 * J;
+        if (tid == 0) {
+            double lj[6][6], y[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                y[c] = v[j0 + c];
+#pragma unroll
+                for (int k = 0; k <= c; k++) lj[c][k] = A[(j0 + c) * n + j0 + k];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double w = y[c];
+#pragma unroll
+                for (int k = 0; k < c; k++) w -= lj[c][k] * y[k];
+                y[c] = w / lj[c][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) v[j0 + c] = y[c];
+        }
+        __syncthreads();
+        for (int i = j0 + 6 + tid; i < n; i += DS_TPB) {
+            const double* li = A + i * n + j0;
+            v[i] -= ((li[0] * v[j0] + li[1] * v[j0 + 1]) + (li[2] * v[j0 + 2] + li[3] * v[j0 + 3])) + (li[4] * v[j0 + 4] + li[5] * v[j0 + 5]);
+        }
+        __syncthreads();
+    }
+    for (int J = nbk - 1; J >= 0; J--) {                                     // L^T x = y  (a single-wave form of the two solves, vector in
+        const int j0 = 6 * J;                                                // registers and no barriers, measured slower: 36 us more per call)
+        if (tid == 0) {
+            double lj[6][6], y[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                y[c] = v[j0 + c];
+#pragma unroll
+                for (int k = 0; k <= c; k++) lj[c][k] = A[(j0 + c) * n + j0 + k];
+            }
+#pragma unroll
+            for (int c = 5; c >= 0; c--) {
+                double w = y[c];
+#pragma unroll
+                for (int k = c + 1; k < 6; k++) w -= lj[k][c] * y[k];
+                y[c] = w / lj[c][c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) v[j0 + c] = y[c];
+        }
+        __syncthreads();
+        for (int i = tid; i < j0; i += DS_TPB) {
+            double w = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) w += A[(j0 + c) * n + i] * v[j0 + c];
+            v[i] -= w;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += DS_TPB) x[i] = v[i];
+    if (tid == 0 && s_bad) atomicOr(bad, 1);
+}
+int dense_small_max() { return DENSE_SMALL_MAX; }
+int dense_launch_small_solve(hipStream_t s, const double* Hb, const int* blk_row, const int* blk_col, int nb, int n, const double* b, double* x, int* bad)
+{
+    const size_t lds = ((size_t)n * n + n) * sizeof(double);
+    if (hipFuncSetAttribute((const void*)k_dense_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_dense_small_solve, dim3(1), dim3(DS_TPB), lds, s, Hb, blk_row, blk_col, nb, n, b, x, bad);
+    return 0;
 }
 
 int dense_pitch(long long n) { return (int)((n + INV_B - 1) / INV_B) * INV_B; }

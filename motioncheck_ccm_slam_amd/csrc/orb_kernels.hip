@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 #define FC_NZ 1024
 #endif
 #ifndef FC_KEPT
-#define FC_KEPT 512
+#define FC_KEPT 480             // + the per-cell bucket counters = the 20480 bytes of LDS that let 8 workgroups share a CU on the 4-cell bands
 #endif
 #define FC_CELLS 32
 #ifndef FC_TPB
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 __host__ __device__ inline int fc_wave_cap(int surv_cap) { return ((surv_cap / 4 + FC_TPB - 1) / FC_TPB) * 256; }
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {
-    return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 12 + 64 * 8;
+    return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 16 + 64 * 8;
 }
 
 
@@ -462,7 +462,7 @@ __device__ __forceinline__ int fc_mbcnt(unsigned long long m, int base)
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
 }
 template <bool PACKED>
-__global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
+__global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
                                                     unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl, int xcd_on)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
@@ -482,11 +482,12 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
     unsigned* kept = reinterpret_cast<unsigned*>(nz + FC_NZ);
     int* cell_hi = reinterpret_cast<int*>(kept + FC_KEPT);   // per cell: local maxima with score >= iniThFAST
     int* cell_n = cell_hi + FC_CELLS;                        // per cell: keypoints written
-    short* clo = reinterpret_cast<short*>(cell_n + FC_CELLS); // per cell: first detection column of the tile, and its width
+    int* cell_k = cell_n + FC_CELLS;                         // per cell: local maxima in the cell's bucket of `kept`
+    short* clo = reinterpret_cast<short*>(cell_k + FC_CELLS); // per cell: first detection column of the tile, and its width
     short* cwd = clo + FC_CELLS;
     uint2* colmask = reinterpret_cast<uint2*>(cwd + FC_CELLS);       // per tile dword: 16-bit lane masks of its detection columns: .x pixels 0 and 2, .y pixels 1 and 3
     if (tid < FC_CELLS) {
-        cell_hi[tid] = 0; cell_n[tid] = 0;
+        cell_hi[tid] = 0; cell_n[tid] = 0; cell_k[tid] = 0;
         if (tid < B.ncells) {
             const OrbCell c = cells[B.cell_first + tid];
             clo[tid] = (short)(c.x0 + 3 - B.xa); cwd[tid] = (short)(c.cw - 6);
@@ -657,6 +658,9 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
     const int rh = bh - 6;
     bool listed = g.min_th <= g.ini_th && nnz <= FC_NZ && B.ncells <= FC_CELLS;
     if (listed) {
+        // the local maxima go to one bucket of `kept` per cell, so that the row-major rank of a keypoint inside its
+        // cell only scans the maxima of that cell (a fifth of the band's on the EuRoC-shaped frames)
+        const int cap_c = ((FC_KEPT / max(B.ncells, 1)) - 1) | 1;      // odd: the buckets start in different LDS banks
         const unsigned p_inv = 0xFFFFFFFFu / (unsigned)P + 1u;           // pos / P == mulhi(pos, p_inv) for pos < 2^16 and every pitch 16..256 (checked exhaustively)
         for (int e = tid; e < nnz; e += FC_TPB) {
             const int pos = nz[e];
@@ -675,24 +679,31 @@ __global__ __launch_bounds__(FC_TPB) void k_fast_cells(const OrbGeom g, const Or
                               sc > NB(d && l, P - 1) && sc > NB(d, P) && sc > NB(d && r, P + 1);
 #undef NB
             if (keep) {
-                const int q = atomicAdd(nsurv + 2, 1);
-                if (q < FC_KEPT) kept[q] = ((unsigned)ci << 20) | ((unsigned)yy << 14) | ((unsigned)xx << 8) | (unsigned)sc;
+                const int q = atomicAdd(cell_k + ci, 1);
+                if (q < cap_c) kept[ci * cap_c + q] = ((unsigned)yy << 14) | ((unsigned)xx << 8) | (unsigned)sc;
                 if (sc >= g.ini_th) atomicAdd(cell_hi + ci, 1);
             }
         }
         __syncthreads();
-        const int nk = nsurv[2];
-        listed = nk <= FC_KEPT;
+        int nk = 0;
+        for (int i = 0; i < B.ncells; i++) {
+            const int k = cell_k[i];
+            listed = listed && k <= cap_c;
+            nk += k;
+        }
         if (listed) {
             for (int e = tid; e < nk; e += FC_TPB) {
-                const unsigned me = kept[e];
-                const int ci = (int)(me >> 20);
+                int ci = 0, k0 = e;
+                for (; k0 >= cell_k[ci]; ci++) k0 -= cell_k[ci];
+                const unsigned* bucket = kept + ci * cap_c;
+                const int nb = cell_k[ci];
+                const unsigned me = bucket[k0];
                 const unsigned th = (unsigned)(cell_hi[ci] > 0 ? g.ini_th : g.min_th);      // :978-984: ini first, else min
                 if ((me & 255u) < th) continue;
                 int rank = 0;                                                             // row-major order inside the cell
-                for (int k = 0; k < nk; k++) {
-                    const unsigned o = kept[k];
-                    rank += ((int)(o >> 20) == ci && (o & 255u) >= th && (o >> 8) < (me >> 8)) ? 1 : 0;
+                for (int k = 0; k < nb; k++) {
+                    const unsigned o = bucket[k];
+                    rank += ((o & 255u) >= th && (o >> 8) < (me >> 8)) ? 1 : 0;
                 }
                 const OrbCell c = cells[B.cell_first + ci];
                 if (rank < c.slot_cap)

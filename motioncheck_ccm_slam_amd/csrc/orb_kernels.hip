@@ -1133,10 +1133,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 // Per-wave LDS: hT[37][46] u16 (horizontally blurred, transposed: column-major so the vertical pass reads
 // a column as 22 consecutive dwords; 92-byte pitch = 23 dwords is odd, hence bank-conflict free) and
-// bl[37][40] u8 (blurred neighbourhood).
+// bl[37][40] u8 (blurred neighbourhood).  bl OVERLAYS hT: the vertical pass has every column in registers
+// before its first store (one wave in lockstep, LDS operations of a wave complete in order), so the
+// workgroup needs 15 KB instead of 21 KB and 8 of them (32 waves) share a CU.
 #define OD_HT_PITCH 92
 #define OD_B_PITCH 40
-#define OD_WAVE_LDS (ORB_BLUR_D * OD_HT_PITCH + ORB_BLUR_D * OD_B_PITCH)      // 3404 + 1480 = 4884
+#define OD_WAVE_LDS (ORB_BLUR_D * OD_HT_PITCH)      // 3404 >= 37 * 40
 #define OD_WAVE_LDS_PAD ((OD_WAVE_LDS + 15) & ~15)
 
 __constant__ signed char c_pattern[1024];
@@ -1150,7 +1152,7 @@ __device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc
 #ifndef OD_WAVES
 #define OD_WAVES 4               // keypoints (waves) per workgroup
 #endif
-__global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
+__global__ __launch_bounds__(64 * OD_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
                                                      const int* __restrict__ sel_count,
                                                      ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                      int* __restrict__ counts, int max_per_image, int* __restrict__ status, int xcd_on)
@@ -1233,7 +1235,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const OrbGeom g, 
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     uint8_t* wl = lds[wv];
-    uint8_t* bl = wl + ORB_BLUR_D * OD_HT_PITCH;
+    uint8_t* bl = wl;                                  // overlays hT, see OD_WAVE_LDS
     // ---- horizontal 7 taps {18,34,49,55,49,34,18}: two v_dot4_u32_u8 per output, written transposed
     if (lane < ORB_PATCH_D) {
         const unsigned Q0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), Q1 = 49u | (34u << 8) | (18u << 16);
@@ -1255,6 +1257,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const OrbGeom g, 
         const unsigned* col = reinterpret_cast<const unsigned*>(wl + lane * OD_HT_PITCH);
 #pragma unroll
         for (int i = 0; i < 22; i++) d[i] = col[i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // every column is in registers before bl overwrites hT
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int y = 0; y < ORB_BLUR_D; y++) {
             const int kk = y >> 1;

@@ -838,73 +838,124 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
     const int N = L.quota;
     int* ocount = out_count + (long long)f * g.nlevels + level;
 
-    // ---- gather this level's candidates in cell-major order into kb[0]
+    // Every loop over keys below is a chain of dependent global-memory round trips, and the kernel's time is the
+    // length of those chains (the level-0 tree of one frame took 100 us with one chunk per trip), so: the chunks
+    // of a loop are dealt to the four waves, and each wave issues the loads of four chunks (or of four small
+    // nodes) before it touches the first.
+    // ---- gather this level's candidates in cell-major order into kb[0]: 64 cells per wave and round
     const int* ccount = cell_count + (long long)f * g.ncells + L.cell_first;
     const unsigned* fslots = slots + (long long)f * g.slots_per_frame;
     int total = 0;
-    for (int base = 0; base < L.ncells; base += 64) {
-        const int ci = base + lane;
-        const int cnt = ci < L.ncells ? ccount[ci] : 0;
-        const int incl = wave_incl_scan(cnt);
-        const int dst = total + incl - cnt;
-        if (cnt > 0) {
-            const unsigned* s = fslots + cells[L.cell_first + ci].slot_first;
-            for (int k = 0; k < cnt; k++)
-                if (wv == 0 && dst + k < L.key_cap) kb[0][dst + k] = s[k];
+    for (int base = 0; base < L.ncells; base += 64 * OCT_WAVES) {
+        int cnt[OCT_WAVES];
+#pragma unroll
+        for (int u = 0; u < OCT_WAVES; u++) {
+            const int ci = base + 64 * u + lane;
+            cnt[u] = ci < L.ncells ? ccount[ci] : 0;
         }
-        total += __shfl(incl, 63, 64);
+        const int myci = base + 64 * wv + lane;
+        const int sfirst = myci < L.ncells ? cells[L.cell_first + myci].slot_first : 0;
+        int mydst = 0, mycnt = 0;
+#pragma unroll
+        for (int u = 0; u < OCT_WAVES; u++) {
+            const int incl = wave_incl_scan(cnt[u]);
+            if (u == wv) { mydst = total + incl - cnt[u]; mycnt = cnt[u]; }
+            total += __shfl(incl, 63, 64);
+        }
+        const unsigned* sp = fslots + sfirst;
+        for (int k = 0; k < mycnt; k += 4) {
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = sp[min(k + u, mycnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (k + u < mycnt && mydst + k + u < L.key_cap) kb[0][mydst + k + u] = v[u];
+        }
     }
     if (total > L.key_cap) { if (lane == 0) atomicOr(status, 1); total = L.key_cap; }
     const int n = total;
-    if (n == 0 || N <= 0) { if (lane == 0) *ocount = 0; return; }
+    if (n == 0 || N <= 0) { if (threadIdx.x == 0) *ocount = 0; return; }
     wave_sync_mem();
 
-    // ---- roots (:711-753): stable partition of all keys by (int)(x / hX) into kb[1]
+    // ---- roots (:711-753): stable partition of all keys by (int)(x / hX) into kb[1]; wave w owns the w-th
+    //      contiguous quarter of the 64-key chunks, its per-root counts go through cc[w][root]
     const int R = L.roots;
-    int rcount[ORB_MAX_ROOTS];
-#pragma unroll
-    for (int r = 0; r < ORB_MAX_ROOTS; r++) rcount[r] = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        int r = -1;
-        if (i < n) { r = (int)((float)key_x(kb[0][i]) / L.hx); r = min(r, R - 1); }
-#pragma unroll
-        for (int q = 0; q < ORB_MAX_ROOTS; q++) rcount[q] += __popcll(__ballot(r == q));
-    }
-    int rbase[ORB_MAX_ROOTS];
+    const int nch = (n + 63) >> 6, cpw = (nch + OCT_WAVES - 1) / OCT_WAVES;
+    const int ch0 = wv * cpw, ch1 = min(nch, ch0 + cpw);
     {
-        int acc = 0;
+        int rc[ORB_MAX_ROOTS];
 #pragma unroll
-        for (int r = 0; r < ORB_MAX_ROOTS; r++) { rbase[r] = acc; acc += rcount[r]; }
-    }
-    {
-        int run[ORB_MAX_ROOTS];
+        for (int r = 0; r < ORB_MAX_ROOTS; r++) rc[r] = 0;
+        for (int ch = ch0; ch < ch1; ch += 4) {
+            unsigned key[4];
 #pragma unroll
-        for (int r = 0; r < ORB_MAX_ROOTS; r++) run[r] = rbase[r];
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            int r = -1; unsigned key = 0;
-            if (i < n) { key = kb[0][i]; r = (int)((float)key_x(key) / L.hx); r = min(r, R - 1); }
+            for (int u = 0; u < 4; u++) {
+                const int i = (ch + u) * 64 + lane;
+                key[u] = (ch + u < ch1 && i < n) ? kb[0][i] : 0xFFFFFFFFu;
+            }
 #pragma unroll
-            for (int q = 0; q < ORB_MAX_ROOTS; q++) {
-                const unsigned long long m = __ballot(r == q);
-                if (wv == 0 && r == q) kb[1][run[q] + __popcll(m & lanemask_lt())] = key;
-                run[q] += __popcll(m);
+            for (int u = 0; u < 4; u++) {
+                const int i = (ch + u) * 64 + lane;
+                int r = -1;
+                if (ch + u < ch1 && i < n) { r = (int)((float)key_x(key[u]) / L.hx); r = min(r, R - 1); }
+#pragma unroll
+                for (int q = 0; q < ORB_MAX_ROOTS; q++) rc[q] += __popcll(__ballot(r == q));
             }
         }
-    }
-    if (threadIdx.x == 0) {
-        int p = 0;
+        if (lane == 0) {
 #pragma unroll
-        for (int r = 0; r < ORB_MAX_ROOTS; r++) {
-            if (r >= R || rcount[r] == 0) continue;
-            cur.x0[p] = (short)(int)(L.hx * (float)r);
-            cur.x1[p] = (short)(int)(L.hx * (float)(r + 1));
-            cur.y0[p] = 0; cur.y1[p] = (short)L.bh;
-            cur.first[p] = rbase[r]; cur.count[p] = rcount[r]; cur.buf[p] = 1;
-            p++;
+            for (int q = 0; q < ORB_MAX_ROOTS; q++) cc[wv * ORB_MAX_ROOTS + q] = rc[q];
         }
-        *shared_len = p;
+    }
+    wave_sync_mem();
+    {
+        int rcount[ORB_MAX_ROOTS], rbase[ORB_MAX_ROOTS], run[ORB_MAX_ROOTS];
+        int acc = 0;
+#pragma unroll
+        for (int q = 0; q < ORB_MAX_ROOTS; q++) {
+            int tot = 0, before = 0;
+#pragma unroll
+            for (int w = 0; w < OCT_WAVES; w++) {
+                const int c = cc[w * ORB_MAX_ROOTS + q];
+                before += w < wv ? c : 0;
+                tot += c;
+            }
+            rcount[q] = tot; rbase[q] = acc; run[q] = acc + before; acc += tot;
+        }
+        const unsigned long long lt = lanemask_lt();
+        for (int ch = ch0; ch < ch1; ch += 4) {
+            unsigned key[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = (ch + u) * 64 + lane;
+                key[u] = (ch + u < ch1 && i < n) ? kb[0][i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = (ch + u) * 64 + lane;
+                int r = -1;
+                if (ch + u < ch1 && i < n) { r = (int)((float)key_x(key[u]) / L.hx); r = min(r, R - 1); }
+#pragma unroll
+                for (int q = 0; q < ORB_MAX_ROOTS; q++) {
+                    const unsigned long long m = __ballot(r == q);
+                    if (r == q) kb[1][run[q] + __popcll(m & lt)] = key[u];
+                    run[q] += __popcll(m);
+                }
+            }
+        }
+        if (threadIdx.x == 0) {                            // (the barrier below also orders these reads of cc before the passes reuse it)
+            int p = 0;
+#pragma unroll
+            for (int r = 0; r < ORB_MAX_ROOTS; r++) {
+                if (r >= R || rcount[r] == 0) continue;
+                cur.x0[p] = (short)(int)(L.hx * (float)r);
+                cur.x1[p] = (short)(int)(L.hx * (float)(r + 1));
+                cur.y0[p] = 0; cur.y1[p] = (short)L.bh;
+                cur.first[p] = rbase[r]; cur.count[p] = rcount[r]; cur.buf[p] = 1;
+                p++;
+            }
+            *shared_len = p;
+        }
     }
     wave_sync_mem();
     int len = *shared_len;
@@ -912,41 +963,108 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
     // ---- refinement passes
     bool finish = false, careful = false;
     int guard = 0;
+    const unsigned long long lt = lanemask_lt();
     while (!finish) {
         if (++guard > 512) { if (lane == 0) atomicOr(status, 2); break; }
         const int prev = len;
-        // (1) child key counts of every node holding more than one key
-        for (int p = 0; p < len; p++) {
-            const int cnt = cur.count[p];
-            if (cnt <= 1 || (p & (OCT_WAVES - 1)) != wv) continue;            // the nodes are dealt to the waves
-            const int sx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;       // x0 + ceil(w/2)  (:652)
-            const int sy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
-            const unsigned* src = kb[cur.buf[p]] + cur.first[p];
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int base = 0; base < cnt; base += 64) {
-                const int i = base + lane;
-                int q = -1;
-                if (i < cnt) {
-                    const unsigned key = src[i];
-                    q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);  // n1,n2,n3,n4 (:684-694)
+        // (1) the nodes holding more than one key, in list order: the full passes divide exactly these, in this
+        //     order.  Every wave builds the whole list and reads back only what it wrote itself.
+        int nc = 0;
+        for (int base = 0; base < len; base += 64) {
+            const int p = base + lane;
+            const bool dv = p < len && cur.count[p] > 1;
+            const unsigned long long m = __ballot(dv);
+            if (dv) ord[nc + __popcll(m & lt)] = p;
+            nc += __popcll(m);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // (2) child key counts AND the stable 4-way partition of every such node's keys into the other scratch
+        //     buffer (DivideNode pushes keys in order, :681-695), four nodes per wave and step.  In careful mode
+        //     some of these nodes are not divided in this pass: their partitioned copy is then simply not used
+        //     (a node's key range belongs to it alone in both buffers, and its `buf` still names the intact one).
+        for (int k0 = wv; k0 < nc; k0 += 4 * OCT_WAVES) {
+            int pp[4], cn[4], sx[4], sy[4], fo[4], pb[4];
+            unsigned k1[4], k2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int kk = k0 + OCT_WAVES * u;
+                pp[u] = 0; cn[u] = 0; sx[u] = 0; sy[u] = 0; fo[u] = 0; pb[u] = 0;
+                if (kk < nc) {
+                    const int p = ord[kk];
+                    pp[u] = p; cn[u] = cur.count[p];
+                    sx[u] = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;       // x0 + ceil(w/2)  (:652)
+                    sy[u] = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
+                    fo[u] = cur.first[p]; pb[u] = cur.buf[p];
                 }
-                c0 += __popcll(__ballot(q == 0)); c1 += __popcll(__ballot(q == 1));
-                c2 += __popcll(__ballot(q == 2)); c3 += __popcll(__ballot(q == 3));
             }
-            if (lane == 0) { cc[4 * p] = c0; cc[4 * p + 1] = c1; cc[4 * p + 2] = c2; cc[4 * p + 3] = c3; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned* src = (pb[u] ? kb[1] : kb[0]) + fo[u];
+                k1[u] = lane < cn[u] ? src[lane] : 0u;
+                k2[u] = lane + 64 < cn[u] ? src[lane + 64] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int cnt = cn[u];
+                if (cnt == 0) continue;
+                const unsigned* src = (pb[u] ? kb[1] : kb[0]) + fo[u];
+                unsigned* dst = (pb[u] ? kb[0] : kb[1]) + fo[u];
+                const int csx = sx[u], csy = sy[u];
+                // n1,n2,n3,n4 (:684-694)
+                const int q1 = lane < cnt ? (key_x(k1[u]) < csx ? 0 : 1) + (key_y(k1[u]) < csy ? 0 : 2) : -1;
+                const int q2 = lane + 64 < cnt ? (key_x(k2[u]) < csx ? 0 : 1) + (key_y(k2[u]) < csy ? 0 : 2) : -1;
+                const unsigned long long a0 = __ballot(q1 == 0), a1 = __ballot(q1 == 1), a2 = __ballot(q1 == 2), a3 = __ballot(q1 == 3);
+                const unsigned long long b0 = __ballot(q2 == 0), b1 = __ballot(q2 == 1), b2 = __ballot(q2 == 2), b3 = __ballot(q2 == 3);
+                int c0 = __popcll(a0) + __popcll(b0), c1 = __popcll(a1) + __popcll(b1);
+                int c2 = __popcll(a2) + __popcll(b2), c3 = __popcll(a3) + __popcll(b3);
+                for (int base = 128; base < cnt; base += 256) {            // a large node (the first passes): count the rest
+                    unsigned key[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int i = base + 64 * j + lane; key[j] = i < cnt ? src[i] : 0u; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int i = base + 64 * j + lane;
+                        const int q = i < cnt ? (key_x(key[j]) < csx ? 0 : 1) + (key_y(key[j]) < csy ? 0 : 2) : -1;
+                        c0 += __popcll(__ballot(q == 0)); c1 += __popcll(__ballot(q == 1));
+                        c2 += __popcll(__ballot(q == 2)); c3 += __popcll(__ballot(q == 3));
+                    }
+                }
+                if (lane == 0) { cc[4 * pp[u]] = c0; cc[4 * pp[u] + 1] = c1; cc[4 * pp[u] + 2] = c2; cc[4 * pp[u] + 3] = c3; }
+                int r0 = 0, r1 = c0, r2 = c0 + c1, r3 = c0 + c1 + c2;
+                if (q1 == 0) dst[r0 + __popcll(a0 & lt)] = k1[u];
+                else if (q1 == 1) dst[r1 + __popcll(a1 & lt)] = k1[u];
+                else if (q1 == 2) dst[r2 + __popcll(a2 & lt)] = k1[u];
+                else if (q1 == 3) dst[r3 + __popcll(a3 & lt)] = k1[u];
+                r0 += __popcll(a0); r1 += __popcll(a1); r2 += __popcll(a2); r3 += __popcll(a3);
+                if (q2 == 0) dst[r0 + __popcll(b0 & lt)] = k2[u];
+                else if (q2 == 1) dst[r1 + __popcll(b1 & lt)] = k2[u];
+                else if (q2 == 2) dst[r2 + __popcll(b2 & lt)] = k2[u];
+                else if (q2 == 3) dst[r3 + __popcll(b3 & lt)] = k2[u];
+                r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
+                for (int base = 128; base < cnt; base += 256) {
+                    unsigned key[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int i = base + 64 * j + lane; key[j] = i < cnt ? src[i] : 0u; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int i = base + 64 * j + lane;
+                        const int q = i < cnt ? (key_x(key[j]) < csx ? 0 : 1) + (key_y(key[j]) < csy ? 0 : 2) : -1;
+                        const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1);
+                        const unsigned long long m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+                        if (q == 0) dst[r0 + __popcll(m0 & lt)] = key[j];
+                        else if (q == 1) dst[r1 + __popcll(m1 & lt)] = key[j];
+                        else if (q == 2) dst[r2 + __popcll(m2 & lt)] = key[j];
+                        else if (q == 3) dst[r3 + __popcll(m3 & lt)] = key[j];
+                        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+                    }
+                }
+            }
         }
         wave_sync_mem();
-        // (2) the divided nodes in processing order: ord[k] = list position of the k-th
-        int nd = 0;
-        if (!careful) {
-            for (int base = 0; base < len; base += 64) {
-                const int p = base + lane;
-                const bool dv = p < len && cur.count[p] > 1;
-                const unsigned long long m = __ballot(dv);
-                if (dv) ord[nd + __popcll(m & lanemask_lt())] = p;
-                nd += __popcll(m);
-            }
-        } else {
+        // (3) the divided nodes in processing order: ord[k] = list position of the k-th
+        int nd = nc;
+        if (careful) {
             // descending (count, creation): new children sit at the list front in reverse creation
             // order, so "created later" == smaller position
             int m_c = 0;
@@ -979,8 +1097,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
             }
             nd = m_c > 0 ? K + 1 : 0;
         }
-        wave_sync_mem();
-        // (3) creation index of each divided node's first child; T = children created in this pass
+        // (4) creation index of each divided node's first child; T = children created in this pass
         int T = 0;
         for (int base = 0; base < nd; base += 64) {
             const int k = base + lane;
@@ -989,18 +1106,20 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
             if (k < nd) cbase[k] = T + incl - ne;
             T += __shfl(incl, 63, 64);
         }
+        // every wave writes all of mark, zeros first: after the barrier each word holds its final value
         for (int base = 0; base < len; base += 64) { const int p = base + lane; if (p < len) mark[p] = 0; }
-        wave_sync_mem();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
         for (int base = 0; base < nd; base += 64) { const int k = base + lane; if (k < nd) mark[ord[k]] = k + 1; }
         wave_sync_mem();
-        // (4) survivors keep their order behind the new children
+        // (5) survivors keep their order behind the new children
         int nsurv = 0;
         for (int base = 0; base < len; base += 64) {
             const int p = base + lane;
             const bool sv = p < len && mark[p] == 0;
             const unsigned long long m = __ballot(sv);
             if (sv) {
-                const int dest = T + nsurv + __popcll(m & lanemask_lt());
+                const int dest = T + nsurv + __popcll(m & lt);
                 if (dest < cap) {
                     nxt.x0[dest] = cur.x0[p]; nxt.y0[dest] = cur.y0[p]; nxt.x1[dest] = cur.x1[p]; nxt.y1[dest] = cur.y1[p];
                     nxt.first[dest] = cur.first[p]; nxt.count[dest] = cur.count[p]; nxt.buf[dest] = cur.buf[p];
@@ -1010,7 +1129,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
         }
         const int newlen = T + nsurv;
         if (newlen > cap) { if (lane == 0) atomicOr(status, 4); break; }
-        // (5) children, pushed to the front one by one: creation index c -> position T-1-c
+        // (6) children, pushed to the front one by one: creation index c -> position T-1-c
         int newExpand = 0;
         for (int base = 0; base < nd; base += 64) {
             const int k = base + lane;
@@ -1040,33 +1159,6 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
             }
             newExpand += wave_sum(gt1);
         }
-        // (6) stable 4-way partition of each divided node's keys into the other scratch buffer
-        for (int k = wv; k < nd; k += OCT_WAVES) {
-            const int p = ord[k];
-            const int cnt = cur.count[p];
-            const int sx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;
-            const int sy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
-            const int pb = cur.buf[p];
-            const unsigned* src = kb[pb] + cur.first[p];
-            unsigned* dst = kb[pb ^ 1] + cur.first[p];
-            int r0 = 0, r1 = cc[4 * p], r2 = r1 + cc[4 * p + 1], r3 = r2 + cc[4 * p + 2];
-            const unsigned long long lt = lanemask_lt();
-            for (int base = 0; base < cnt; base += 64) {
-                const int i = base + lane;
-                int q = -1; unsigned key = 0;
-                if (i < cnt) {
-                    key = src[i];
-                    q = (key_x(key) < sx ? 0 : 1) + (key_y(key) < sy ? 0 : 2);
-                }
-                const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1);
-                const unsigned long long m2 = __ballot(q == 2), m3 = __ballot(q == 3);
-                if (q == 0) dst[r0 + __popcll(m0 & lt)] = key;
-                else if (q == 1) dst[r1 + __popcll(m1 & lt)] = key;
-                else if (q == 2) dst[r2 + __popcll(m2 & lt)] = key;
-                else if (q == 3) dst[r3 + __popcll(m3 & lt)] = key;
-                r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
-            }
-        }
         wave_sync_mem();
         { OctNodes t = cur; cur = nxt; nxt = t; }
         len = newlen;
@@ -1083,9 +1175,13 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
             const unsigned* src = kb[cur.buf[p]] + cur.first[p];
             const int cnt = cur.count[p];
             unsigned best = src[0];
-            for (int k = 1; k < cnt; k++) {
-                const unsigned key = src[k];
-                if ((key >> 24) > (best >> 24)) best = key;
+            for (int k = 1; k < cnt; k += 4) {
+                unsigned key[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) key[u] = src[min(k + u, cnt - 1)];     // a repeated last key never replaces (strict >)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if ((key[u] >> 24) > (best >> 24)) best = key[u];
             }
             o[p] = best;
         }

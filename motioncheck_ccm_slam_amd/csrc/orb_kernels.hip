@@ -1067,12 +1067,12 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
         if (careful) {
             // descending (count, creation): new children sit at the list front in reverse creation
             // order, so "created later" == smaller position
-            int m_c = 0;
-            for (int base = 0; base < len; base += 64) {
+            // (the quadratic rank loop is most of this kernel's instructions: each wave ranks a quarter of the list)
+            const int m_c = nc;
+            for (int base = 64 * wv; base < len; base += 64 * OCT_WAVES) {
                 const int p = base + lane;
                 const int myc = p < len ? cur.count[p] : 0;
-                const bool cand = myc > 1;
-                if (cand) {
+                if (myc > 1) {
                     int rank = 0;
                     for (int q = 0; q < len; q++) {
                         const int cq = cur.count[q];
@@ -1081,7 +1081,6 @@ __global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, cons
                     ord[rank] = p;
                     gain[rank] = oct_nonempty(cc, p) - 1;
                 }
-                m_c += __popcll(__ballot(cand));
             }
             wave_sync_mem();
             // stop after the first node that brings the list to N (:898); otherwise divide all

@@ -1345,25 +1345,39 @@ __global__ __launch_bounds__(64 * OD_WAVES) __attribute__((amdgpu_waves_per_eu(8
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    // ---- vertical 7 taps + the single rounding: lane c < 37 owns blurred column c; rows are packed two per
-    //      dword so four v_dot2_u32_u16 make one output
-    if (lane < ORB_BLUR_D) {
-        unsigned d[22];
-        const unsigned* col = reinterpret_cast<const unsigned*>(wl + lane * OD_HT_PITCH);
+    // ---- vertical 7 taps + the single rounding.  An item is a third of a blurred column (rows 12t .. 12t+12; the
+    //      13th row of the first two thirds is also the first of the next: same value, written twice): 111 items in
+    //      two rounds of 64 lanes = 26 outputs per lane instead of 37.  Rows are packed two per dword, so four
+    //      v_dot2_u32_u16 make one output; a third starts on an even row, so the tap layout is the same for all.
+    {
+        unsigned d[2][10];
+        int wofs[2];
 #pragma unroll
-        for (int i = 0; i < 22; i++) d[i] = col[i];
+        for (int rd = 0; rd < 2; rd++) {
+            const int item = min(rd * 64 + lane, 3 * ORB_BLUR_D - 1);
+            const int c = (item * 171) >> 9, t = item - 3 * c;                 // item / 3 for item < 128
+            const unsigned* col = reinterpret_cast<const unsigned*>(wl + c * OD_HT_PITCH) + 6 * t;
+#pragma unroll
+            for (int i = 0; i < 10; i++) d[rd][i] = col[i];
+            wofs[rd] = 12 * t * OD_B_PITCH + c;
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);                // every column is in registers before bl overwrites hT
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int y = 0; y < ORB_BLUR_D; y++) {
-            const int kk = y >> 1;
-            unsigned v;
-            if ((y & 1) == 0)
-                v = od_dot2(d[kk + 3], 18u, od_dot2(d[kk + 2], 49u | (34u << 16), od_dot2(d[kk + 1], 49u | (55u << 16), od_dot2(d[kk], 18u | (34u << 16), 32768u))));
-            else
-                v = od_dot2(d[kk + 3], 34u | (18u << 16), od_dot2(d[kk + 2], 55u | (49u << 16), od_dot2(d[kk + 1], 34u | (49u << 16), od_dot2(d[kk], 18u << 16, 32768u))));
-            bl[y * OD_B_PITCH + lane] = (uint8_t)min(v >> 16, 255u);     // the rounding constant 32768 is the accumulator's start value
+        for (int rd = 0; rd < 2; rd++) {
+            if (rd * 64 + lane < 3 * ORB_BLUR_D) {
+#pragma unroll
+                for (int y = 0; y < 13; y++) {
+                    const int kk = y >> 1;
+                    unsigned v;
+                    if ((y & 1) == 0)
+                        v = od_dot2(d[rd][kk + 3], 18u, od_dot2(d[rd][kk + 2], 49u | (34u << 16), od_dot2(d[rd][kk + 1], 49u | (55u << 16), od_dot2(d[rd][kk], 18u | (34u << 16), 32768u))));
+                    else
+                        v = od_dot2(d[rd][kk + 3], 34u | (18u << 16), od_dot2(d[rd][kk + 2], 55u | (49u << 16), od_dot2(d[rd][kk + 1], 34u | (49u << 16), od_dot2(d[rd][kk], 18u << 16, 32768u))));
+                    bl[wofs[rd] + y * OD_B_PITCH] = (uint8_t)min(v >> 16, 255u);     // the rounding constant 32768 is the accumulator's start value
+                }
+            }
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double* __restrict__
 // end -- is fixed: reproducible run to run.
 typedef double sp_v4d __attribute__((ext_vector_type(4)));
 template <int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                                                          const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb,
                                                          double* __restrict__ Hb)

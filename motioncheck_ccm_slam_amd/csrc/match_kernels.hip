@@ -585,15 +585,23 @@ void match_launch_window_select(hipStream_t s, const WinGrid& G, int nq, const f
     hipLaunchKernelGGL(k_window_select, dim3((nq + 3) / 4), dim3(256), 0, s, G, nq, qx, qy, qr, minl, maxl, qdesc, inv_sigma2, accept_th, best_idx, best_dist);
 }
 
-// k_window_greedy: the ORDER-DEPENDENT acceptance of SearchByProjection(Frame&, vpMapPoints) (ORBmatcher.cpp:71-148, MODE 0) and
-// SearchByProjection(pKF, Scw, vpPoints, vpMatched) (:308-446, MODE 1) on the candidate lists k_window_candidates left in HBM.
-// The reference visits the map points one after the other and a point's choice depends on which features earlier points have
-// taken (`occupied` / `vpMatched`).  Equivalent parallel form: in every round each unresolved point claims its still-free
-// candidates with atomicMin(claim[feature], point); a point that holds the claim on ALL of them is the earliest unresolved point
-// touching any of its candidates, so nothing can change its inputs any more: it decides exactly as the sequential loop would.
-// Points resolved in one round have disjoint candidates (no write conflict); the lowest unresolved point always resolves, so
-// the loop ends, and after WG_MAX_ROUNDS (chains of points sharing one window) one wave finishes the rest in order, a candidate per lane.
-// One workgroup; claim / flag / resolved live in LDS.
+// k_window_greedy: the ORDER-DEPENDENT acceptance of SearchByProjection(Frame&, vpMapPoints) (ORBmatcher.cpp:71-148, MODE 0),
+// SearchByProjection(pKF, Scw, vpPoints, vpMatched) (:308-446, MODE 1) and SearchByProjection(CurrentFrame, LastFrame / KeyFrame)
+// (:1350-1476, :1478-1605, MODE 2) on the candidate lists k_window_candidates left in HBM.
+// The reference visits the map points one after the other, and a point's choice depends on which features earlier points have
+// taken (`occupied` / `vpMatched` / the frame's map-point slots).  A point takes the nearest of its still-free candidates (MODE 0
+// also looks at the second nearest for the ratio test), and flags are only ever SET.  Hence the parallel form used here:
+//   an unresolved point may decide as soon as NO EARLIER unresolved point has the feature it would take (MODE 0: the two it
+//   looks at) among its own free candidates.  Flags that earlier points set later can then only fall on candidates this point
+//   does not look at -- removing them changes neither its minimum nor the list order of the rest -- and the flag this point sets
+//   falls on a feature no earlier unresolved point can choose.  "No acceptable candidate" is final at once: candidates only vanish.
+// The earliest unresolved point always decides, so the rounds end.
+// Layout: one workgroup of 16 waves; 1024 consecutive points per batch, thread = point, its first 16 candidates (feature | distance)
+// in registers -- all global loads of a batch are issued by all threads at once; then the waves take turns in point order, and inside
+// a wave the rounds need no workgroup barrier: claim[feature] = lowest lane among the unresolved lanes that have the feature free
+// (LDS atomicMin), decide where the claim on the wanted feature(s) is one's own, reset the claims.  With many points per feature
+// (20,000 points on a 1,000-feature keyframe) round 2's first version -- claims on ALL free candidates over the whole list, 48 rounds,
+// then one wave visiting the rest in order with two global round trips per point -- took 9.1 ms; this takes the same decisions.
 struct GreedyArgs {
     int nq, n, cap;
     const int* ci; const int* cd; const int* cn;      // candidate lists [nq][cap], counts
@@ -603,181 +611,133 @@ struct GreedyArgs {
     uint8_t* flag;                                    // in/out per feature: occupied / matched
     float nnratio;
     int* out;                                         // MODE 0 / 2: match[feature] = point; MODE 1: best_idx[point] = feature
-    int* status;                                      // [0] matches (or -1: a list overflowed), [1] longest list, [2] rounds
-    // MODE 2 (SearchByProjection(CurrentFrame, LastFrame / KeyFrame), ORBmatcher.cpp:1350-1476, :1478-1605): acceptance threshold,
-    // rotation check and its inputs; ev[point] = accepted feature << 8 | rotation bin (or -1)
+    int* status;                                      // [0] matches (or -1: a list overflowed), [1] longest list, [2] most rounds a wave needed
+    // MODE 2: acceptance threshold, rotation check and its inputs; ev[point] = accepted feature << 8 | rotation bin (or -1)
     int orb_dist, check_ori; const float* q_angle; const float* f_angle; int* ev;
 };
-#define WG_MAX_ROUNDS 48
-template <int MODE>
-__device__ __forceinline__ int wg_decide(const GreedyArgs& A, int m, uint8_t* flag)
-{
-    const int c = A.cn[m];
-    const int* ci = A.ci + (long long)m * A.cap; const int* cd = A.cd + (long long)m * A.cap;
-    if (MODE == 0) {
-        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-        for (int k = 0; k < c; k++) {
-            const int idx = ci[k];
-            if (flag[idx]) continue;
-            const int dist = cd[k];
-            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = A.oct[idx]; bestIdx = idx; }
-            else if (dist < bestDist2) { bestLevel2 = A.oct[idx]; bestDist2 = dist; }
-        }
-        if (bestDist <= 100) {                                                  // TH_HIGH
-            if (bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2) return 0;
-            A.out[bestIdx] = m;
-            flag[bestIdx] = A.qflag[m];
-            return 1;
-        }
-        return 0;
-    } else if (MODE == 2) {
-        int bestDist = 256, bestIdx = -1;
-        for (int k = 0; k < c; k++) {
-            const int idx = ci[k];
-            if (flag[idx]) continue;                                            // :1419-1421
-            const int dist = cd[k];
-            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-        }
-        A.ev[m] = -1;
-        if (bestDist <= A.orb_dist) {                                           // TH_HIGH (:1432) / ORBdist (:1556)
-            A.out[bestIdx] = m;
-            flag[bestIdx] = A.qflag[m];
-            int bin = 255;
-            if (A.check_ori) {                                                  // :1437-1447
-                float rot = A.q_angle[m] - A.f_angle[bestIdx];
-                if (rot < 0.0) rot += 360.0f;
-                bin = (int)roundf(rot * (1.0f / 30));
-                if (bin == 30) bin = 0;
-            }
-            A.ev[m] = (bestIdx << 8) | bin;
-            return 1;
-        }
-        return 0;
-    } else {
-        const int lvl = A.qlevel[m];
-        int bestDist = 256, bestIdx = -1;
-        for (int k = 0; k < c; k++) {
-            const int idx = ci[k];
-            if (flag[idx]) continue;                                            // :394
-            const int kpLevel = A.oct[idx];
-            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
-            const int dist = cd[k];
-            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
-        }
-        if (bestDist <= 50) {                                                   // TH_LOW
-            A.out[m] = bestIdx;
-            if (!A.qflag[m]) { flag[bestIdx] = 1; return 1; }                   // :436-440
-        }
-        return 0;
-    }
-}
-// The same decision taken by ONE WAVE for one point: lane = candidate (lists longer than 64 in chunks), the two smallest
-// (distance, position) keys by wave reductions -- the sequential scan's `dist < bestDist` / `else if dist < bestDist2` keeps exactly
-// the first and second element in (distance, position) order.  Used for the points the claim rounds leave unresolved (many points
-// competing for the same features): they have to be visited in order anyway, but each visit costs ~60 wave-instructions instead
-// of a scalar walk over the list.
-__device__ __forceinline__ unsigned wg_wave_min(unsigned v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
-    return v;
-}
-template <int MODE>
-__device__ __forceinline__ int wg_decide_wave(const GreedyArgs& A, int m, uint8_t* flag, int lane)
-{
-    if (MODE == 2) { int r = 0; if (lane == 0) r = wg_decide<2>(A, m, flag); return r; }      // in-order pass of the frame matcher: one lane
-    const int c = A.cn[m];
-    const int* ci = A.ci + (long long)m * A.cap; const int* cd = A.cd + (long long)m * A.cap;
-    const int lvl = MODE == 1 ? A.qlevel[m] : 0;
-    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;                 // running best / second: dist << 16 | position
-    for (int base = 0; base < c; base += 64) {
-        const int k = base + lane;
-        unsigned key = 0xFFFFFFFFu;
-        if (k < c) {
-            const int idx = ci[k];
-            bool ok = !flag[idx];
-            if (MODE == 1) { const int kl = A.oct[idx]; ok = ok && !(kl < lvl - 1 || kl > lvl); }
-            if (ok) key = ((unsigned)cd[k] << 16) | (unsigned)k;
-        }
-        const unsigned b1 = wg_wave_min(key);
-        const unsigned b2 = wg_wave_min(key == b1 ? 0xFFFFFFFFu : key);      // keys are distinct (position), so this drops one lane
-        // merge {k1, k2} with {b1, b2}
-        const unsigned lo = k1 < b1 ? k1 : b1, hi = k1 < b1 ? b1 : k1;
-        const unsigned other = k1 < b1 ? k2 : b2;
-        k1 = lo; k2 = hi < other ? hi : other;
-    }
-    int result = 0;
-    if (lane == 0) {
-        const int bestDist = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16), bestDist2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 16);
-        if (MODE == 0) {
-            if (bestDist <= 100) {
-                const int bestIdx = ci[k1 & 0xFFFFu];
-                const int bestLevel = A.oct[bestIdx], bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : A.oct[ci[k2 & 0xFFFFu]];
-                if (!(bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2)) { A.out[bestIdx] = m; flag[bestIdx] = A.qflag[m]; result = 1; }
-            }
-        } else if (bestDist <= 50) {
-            const int bestIdx = ci[k1 & 0xFFFFu];
-            A.out[m] = bestIdx;
-            if (!A.qflag[m]) { flag[bestIdx] = 1; result = 1; }
-        }
-    }
-    return result;                                                // valid in lane 0
-}
+#define WG_REG_CAND 16
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
 {
     extern __shared__ int wg_lds[];
     int* claim = wg_lds;                                            // [n]
     uint8_t* flag = reinterpret_cast<uint8_t*>(claim + A.n);        // [n]
-    uint8_t* resolved = flag + ((A.n + 3) & ~3);                    // [nq]
-    __shared__ int s_left, s_count, s_maxcn;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_count = 0; s_maxcn = 0; }
-    for (int i = tid; i < A.n; i += 1024) flag[i] = A.flag[i];
+    uint8_t* octl = flag + ((A.n + 3) & ~3);                        // [n] octave per feature
+    __shared__ int s_count, s_maxcn, s_rounds;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_count = 0; s_maxcn = 0; s_rounds = 0; }
+    for (int i = tid; i < A.n; i += 1024) { flag[i] = A.flag[i]; octl[i] = (uint8_t)A.oct[i]; claim[i] = 0x7FFFFFFF; }
     __syncthreads();
     int mx = 0;
-    for (int m = tid; m < A.nq; m += 1024) { const int c = A.cn[m]; mx = max(mx, c); resolved[m] = (!A.active[m] || c == 0) ? 1 : 0; }
+    for (int m = tid; m < A.nq; m += 1024) mx = max(mx, A.cn[m]);
     atomicMax(&s_maxcn, mx);
     __syncthreads();
     if (s_maxcn > A.cap) { if (tid == 0) { A.status[0] = -1; A.status[1] = s_maxcn; A.status[2] = 0; } return; }   // the host retries with longer lists
-    int round = 0;
-    for (;; round++) {
-        for (int i = tid; i < A.n; i += 1024) claim[i] = 0x7FFFFFFF;
-        if (tid == 0) s_left = 0;
-        __syncthreads();
-        if (round >= WG_MAX_ROUNDS) {
-            if (tid < 64) {                                        // wave 0 visits the rest in order
-                int cnt = 0;
-                for (int m = 0; m < A.nq; m++) {
-                    if (resolved[m]) continue;
-                    cnt += wg_decide_wave<MODE>(A, m, flag, tid);
-                    __builtin_amdgcn_wave_barrier();               // lane 0's flag write precedes the next point's reads (LDS, in order within the wave)
+    int mine = 0, most = 0;
+    for (int base = 0; base < A.nq; base += 1024) {
+        const int m = base + tid;
+        int c = 0, lvl = 0, qf = 0;
+        unsigned cand[WG_REG_CAND];                                  // feature | distance << 16
+        if (m < A.nq && A.active[m]) c = A.cn[m];
+        const int* ci = A.ci + (long long)min(m, A.nq - 1) * A.cap; const int* cd = A.cd + (long long)min(m, A.nq - 1) * A.cap;
+#pragma unroll
+        for (int k = 0; k < WG_REG_CAND; k++) cand[k] = k < c ? ((unsigned)ci[k] | ((unsigned)cd[k] << 16)) : 0u;
+        if (c > 0) { qf = A.qflag[m]; if (MODE == 1) lvl = A.qlevel[m]; }
+        if (MODE == 2 && m < A.nq) A.ev[m] = -1;
+        // candidate k of this point is free and of a level the point may take
+        auto usable = [&](int idx) -> bool {
+            if (flag[idx]) return false;
+            if (MODE == 1) { const int kl = octl[idx]; if (kl < lvl - 1 || kl > lvl) return false; }      // :394-400
+            return true;
+        };
+        for (int turn = 0; turn < 16; turn++) {
+            if (wv == turn) {
+                bool unres = c > 0;
+                int rounds = 0;
+                while (__ballot(unres) != 0ull) {
+                    rounds++;
+                    // nearest and second nearest usable candidate in (distance, list position) order: what the sequential scan's
+                    // `dist < bestDist` / `else if dist < bestDist2` keeps; and the claims
+                    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+                    if (unres) {
+#pragma unroll
+                        for (int k = 0; k < WG_REG_CAND; k++) {
+                            if (k < c) {
+                                const int idx = (int)(cand[k] & 0xFFFFu);
+                                if (usable(idx)) {
+                                    atomicMin(&claim[idx], lane);
+                                    const unsigned key = (cand[k] & 0xFFFF0000u) | (unsigned)k;
+                                    if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                                }
+                            }
+                        }
+                        for (int k = WG_REG_CAND; k < c; k++) {
+                            const int idx = ci[k];
+                            if (usable(idx)) {
+                                atomicMin(&claim[idx], lane);
+                                const unsigned key = ((unsigned)cd[k] << 16) | (unsigned)k;
+                                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    const int th = MODE == 0 ? 100 : (MODE == 1 ? 50 : A.orb_dist);       // TH_HIGH / TH_LOW / TH_HIGH or ORBdist
+                    const int bestDist = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16);
+                    int idx1 = -1, idx2 = -1;
+                    bool safe = false;
+                    if (unres) {
+                        if (bestDist > th) safe = true;                                     // no acceptable candidate: final
+                        else {
+                            const int p1 = (int)(k1 & 0xFFFFu);
+                            idx1 = ci[p1];
+                            safe = claim[idx1] == lane;
+                            if (MODE == 0 && k2 != 0xFFFFFFFFu) { idx2 = ci[(int)(k2 & 0xFFFFu)]; safe = safe && claim[idx2] == lane; }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    if (unres) {                                                            // claims back to "nobody"
+#pragma unroll
+                        for (int k = 0; k < WG_REG_CAND; k++) if (k < c) claim[cand[k] & 0xFFFFu] = 0x7FFFFFFF;
+                        for (int k = WG_REG_CAND; k < c; k++) claim[ci[k]] = 0x7FFFFFFF;
+                    }
+                    if (unres && safe) {
+                        unres = false;
+                        if (bestDist <= th) {
+                            if (MODE == 0) {
+                                const int bestLevel = octl[idx1], bestLevel2 = idx2 >= 0 ? (int)octl[idx2] : -1;
+                                const int bestDist2 = idx2 >= 0 ? (int)(k2 >> 16) : 256;
+                                if (!(bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2)) { A.out[idx1] = m; flag[idx1] = (uint8_t)qf; mine++; }
+                            } else if (MODE == 1) {
+                                A.out[m] = idx1;
+                                if (!qf) { flag[idx1] = 1; mine++; }                        // :436-440
+                            } else {
+                                A.out[idx1] = m;
+                                flag[idx1] = (uint8_t)qf;
+                                int bin = 255;
+                                if (A.check_ori) {                                          // :1437-1447
+                                    float rot = A.q_angle[m] - A.f_angle[idx1];
+                                    if (rot < 0.0) rot += 360.0f;
+                                    bin = (int)roundf(rot * (1.0f / 30));
+                                    if (bin == 30) bin = 0;
+                                }
+                                A.ev[m] = (idx1 << 8) | bin;
+                                mine++;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
                 }
-                if (tid == 0) s_count += cnt;
+                most = max(most, rounds);
             }
             __syncthreads();
-            break;
         }
-        for (int m = tid; m < A.nq; m += 1024) {
-            if (resolved[m]) continue;
-            const int c = A.cn[m]; const int* ci = A.ci + (long long)m * A.cap;
-            for (int k = 0; k < c; k++) { const int idx = ci[k]; if (!flag[idx]) atomicMin(&claim[idx], m); }
-        }
-        __syncthreads();
-        int mine = 0, left = 0;
-        for (int m = tid; m < A.nq; m += 1024) {
-            if (resolved[m]) continue;
-            const int c = A.cn[m]; const int* ci = A.ci + (long long)m * A.cap;
-            bool fin = true;
-            for (int k = 0; k < c && fin; k++) { const int idx = ci[k]; fin = flag[idx] || claim[idx] == m; }
-            if (fin) { mine += wg_decide<MODE>(A, m, flag); resolved[m] = 1; } else left++;
-        }
-        if (mine) atomicAdd(&s_count, mine);
-        if (left) atomicAdd(&s_left, left);
-        __syncthreads();
-        if (s_left == 0) break;
-        __syncthreads();                                             // everybody has read s_left before it is reset
     }
+    if (mine) atomicAdd(&s_count, mine);
+    atomicMax(&s_rounds, most);
+    __syncthreads();
     if (MODE == 2 && A.check_ori) {
         // rotation consistency (:1453-1471): histogram of the accepted matches' angle differences, the three largest bins stay
         // (ComputeThreeMaxima :1607-1648), every match recorded in another bin is cleared -- also when a later point re-took the feature
@@ -813,9 +773,9 @@ __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
         __syncthreads();
     }
     for (int i = tid; i < A.n; i += 1024) A.flag[i] = flag[i];
-    if (tid == 0) { A.status[0] = s_count; A.status[1] = s_maxcn; A.status[2] = round; }
+    if (tid == 0) { A.status[0] = s_count; A.status[1] = s_maxcn; A.status[2] = s_rounds; }
 }
-size_t match_window_greedy_lds(int n, int nq) { return (size_t)4 * n + ((n + 3) & ~3) + nq + 16; }
+size_t match_window_greedy_lds(int n, int nq) { (void)nq; return (size_t)4 * n + 2 * (size_t)((n + 3) & ~3) + 16; }
 int match_launch_window_greedy(hipStream_t s, int mode, const GreedyArgs& A)
 {
     const size_t lds = match_window_greedy_lds(A.n, A.nq);

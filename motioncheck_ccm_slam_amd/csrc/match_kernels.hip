@@ -616,6 +616,7 @@ struct GreedyArgs {
     int orb_dist, check_ori; const float* q_angle; const float* f_angle; int* ev;
 };
 #define WG_REG_CAND 16
+#define WG_BATCH_ROUNDS 3
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
 {
@@ -650,90 +651,113 @@ __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
             if (MODE == 1) { const int kl = octl[idx]; if (kl < lvl - 1 || kl > lvl) return false; }      // :394-400
             return true;
         };
-        for (int turn = 0; turn < 16; turn++) {
-            if (wv == turn) {
-                bool unres = c > 0;
-                int rounds = 0;
-                while (__ballot(unres) != 0ull) {
-                    rounds++;
-                    // nearest and second nearest usable candidate in (distance, list position) order: what the sequential scan's
-                    // `dist < bestDist` / `else if dist < bestDist2` keeps; and the claims
-                    unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-                    if (unres) {
+        // one claim round for the unresolved points: `me` orders them (thread id inside the batch, or lane inside a wave); WG selects
+        // the workgroup barrier (all 1024 points at once) or the wave barrier (one wave on its turn)
+        bool unres = c > 0;
+        auto sync = [&](bool wg) {
+            if (wg) __syncthreads();
+            else { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+        };
+        auto round = [&](int me, bool wg) {
+            // nearest and second nearest usable candidate in (distance, list position) order: what the sequential scan's
+            // `dist < bestDist` / `else if dist < bestDist2` keeps; and the claims
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            if (unres) {
 #pragma unroll
-                        for (int k = 0; k < WG_REG_CAND; k++) {
-                            if (k < c) {
-                                const int idx = (int)(cand[k] & 0xFFFFu);
-                                if (usable(idx)) {
-                                    atomicMin(&claim[idx], lane);
-                                    const unsigned key = (cand[k] & 0xFFFF0000u) | (unsigned)k;
-                                    if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-                                }
-                            }
-                        }
-                        for (int k = WG_REG_CAND; k < c; k++) {
-                            const int idx = ci[k];
-                            if (usable(idx)) {
-                                atomicMin(&claim[idx], lane);
-                                const unsigned key = ((unsigned)cd[k] << 16) | (unsigned)k;
-                                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-                            }
+                for (int k = 0; k < WG_REG_CAND; k++) {
+                    if (k < c) {
+                        const int idx = (int)(cand[k] & 0xFFFFu);
+                        if (usable(idx)) {
+                            atomicMin(&claim[idx], me);
+                            const unsigned key = (cand[k] & 0xFFFF0000u) | (unsigned)k;
+                            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
                         }
                     }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                    const int th = MODE == 0 ? 100 : (MODE == 1 ? 50 : A.orb_dist);       // TH_HIGH / TH_LOW / TH_HIGH or ORBdist
-                    const int bestDist = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16);
-                    int idx1 = -1, idx2 = -1;
-                    bool safe = false;
-                    if (unres) {
-                        if (bestDist > th) safe = true;                                     // no acceptable candidate: final
-                        else {
-                            const int p1 = (int)(k1 & 0xFFFFu);
-                            idx1 = ci[p1];
-                            safe = claim[idx1] == lane;
-                            if (MODE == 0 && k2 != 0xFFFFFFFFu) { idx2 = ci[(int)(k2 & 0xFFFFu)]; safe = safe && claim[idx2] == lane; }
-                        }
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                    if (unres) {                                                            // claims back to "nobody"
-#pragma unroll
-                        for (int k = 0; k < WG_REG_CAND; k++) if (k < c) claim[cand[k] & 0xFFFFu] = 0x7FFFFFFF;
-                        for (int k = WG_REG_CAND; k < c; k++) claim[ci[k]] = 0x7FFFFFFF;
-                    }
-                    if (unres && safe) {
-                        unres = false;
-                        if (bestDist <= th) {
-                            if (MODE == 0) {
-                                const int bestLevel = octl[idx1], bestLevel2 = idx2 >= 0 ? (int)octl[idx2] : -1;
-                                const int bestDist2 = idx2 >= 0 ? (int)(k2 >> 16) : 256;
-                                if (!(bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2)) { A.out[idx1] = m; flag[idx1] = (uint8_t)qf; mine++; }
-                            } else if (MODE == 1) {
-                                A.out[m] = idx1;
-                                if (!qf) { flag[idx1] = 1; mine++; }                        // :436-440
-                            } else {
-                                A.out[idx1] = m;
-                                flag[idx1] = (uint8_t)qf;
-                                int bin = 255;
-                                if (A.check_ori) {                                          // :1437-1447
-                                    float rot = A.q_angle[m] - A.f_angle[idx1];
-                                    if (rot < 0.0) rot += 360.0f;
-                                    bin = (int)roundf(rot * (1.0f / 30));
-                                    if (bin == 30) bin = 0;
-                                }
-                                A.ev[m] = (idx1 << 8) | bin;
-                                mine++;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
                 }
-                most = max(most, rounds);
+                for (int k = WG_REG_CAND; k < c; k++) {
+                    const int idx = ci[k];
+                    if (usable(idx)) {
+                        atomicMin(&claim[idx], me);
+                        const unsigned key = ((unsigned)cd[k] << 16) | (unsigned)k;
+                        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                    }
+                }
             }
-            __syncthreads();
+            sync(wg);
+            const int th = MODE == 0 ? 100 : (MODE == 1 ? 50 : A.orb_dist);       // TH_HIGH / TH_LOW / TH_HIGH or ORBdist
+            const int bestDist = k1 == 0xFFFFFFFFu ? 256 : (int)(k1 >> 16);
+            int idx1 = -1, idx2 = -1;
+            bool safe = false;
+            if (unres) {
+                if (bestDist > th) safe = true;                                     // no acceptable candidate: final
+                else {
+                    const int p1 = (int)(k1 & 0xFFFFu), p2 = (int)(k2 & 0xFFFFu);
+                    if (p1 >= WG_REG_CAND) idx1 = ci[p1];
+                    if (MODE == 0 && k2 != 0xFFFFFFFFu && p2 >= WG_REG_CAND) idx2 = ci[p2];
+#pragma unroll
+                    for (int k = 0; k < WG_REG_CAND; k++) {
+                        if (k == p1) idx1 = (int)(cand[k] & 0xFFFFu);
+                        if (MODE == 0 && k2 != 0xFFFFFFFFu && k == p2) idx2 = (int)(cand[k] & 0xFFFFu);
+                    }
+                    safe = claim[idx1] == me;
+                    if (MODE == 0 && idx2 >= 0) safe = safe && claim[idx2] == me;
+                }
+            }
+            sync(wg);
+            if (unres) {                                                            // claims back to "nobody"
+#pragma unroll
+                for (int k = 0; k < WG_REG_CAND; k++) if (k < c) claim[cand[k] & 0xFFFFu] = 0x7FFFFFFF;
+                for (int k = WG_REG_CAND; k < c; k++) claim[ci[k]] = 0x7FFFFFFF;
+            }
+            if (unres && safe) {
+                unres = false;
+                if (bestDist <= th) {
+                    if (MODE == 0) {
+                        const int bestLevel = octl[idx1], bestLevel2 = idx2 >= 0 ? (int)octl[idx2] : -1;
+                        const int bestDist2 = idx2 >= 0 ? (int)(k2 >> 16) : 256;
+                        if (!(bestLevel == bestLevel2 && bestDist > A.nnratio * bestDist2)) { A.out[idx1] = m; flag[idx1] = (uint8_t)qf; mine++; }
+                    } else if (MODE == 1) {
+                        A.out[m] = idx1;
+                        if (!qf) { flag[idx1] = 1; mine++; }                        // :436-440
+                    } else {
+                        A.out[idx1] = m;
+                        flag[idx1] = (uint8_t)qf;
+                        int bin = 255;
+                        if (A.check_ori) {                                          // :1437-1447
+                            float rot = A.q_angle[m] - A.f_angle[idx1];
+                            if (rot < 0.0) rot += 360.0f;
+                            bin = (int)roundf(rot * (1.0f / 30));
+                            if (bin == 30) bin = 0;
+                        }
+                        A.ev[m] = (idx1 << 8) | bin;
+                        mine++;
+                    }
+                }
+            }
+        };
+        // (1) a few rounds over the whole batch: with few points per feature nearly every point decides here
+        int left = 1, rounds = 0;
+        for (int r = 0; r < WG_BATCH_ROUNDS && left; r++) {
+            round(tid, true);
+            left = __syncthreads_count(unres ? 1 : 0);                              // also: flags and claim resets visible to all
+            rounds++;
         }
+        // (2) what is left (many points wanting the same features) is finished wave by wave, in point order, without workgroup barriers
+        //     inside a wave's turn
+        if (left) {
+            for (int turn = 0; turn < 16; turn++) {
+                if (wv == turn) {
+                    while (__ballot(unres) != 0ull) {
+                        rounds++;
+                        round(lane, false);
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        most = max(most, rounds);
     }
     if (mine) atomicAdd(&s_count, mine);
     atomicMax(&s_rounds, most);

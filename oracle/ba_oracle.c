@@ -1058,8 +1058,13 @@ static void ess_error(const double* C, const double* Si, const double* Sj, doubl
     orc_sim3_log(t2, e);
 }
 
-/* sim3 [n][8] in/out; fixed[n]; edges (ei[k] = vertex 0, ej[k] = vertex 1, meas[k] = Sji).  Dense normal equations
- * (the reference's sparse Cholesky solves the same system).  Returns the iterations done; chi2 in out[0..1]. */
+/* Solver of the pose graph's normal equations: 0 automatic (block-sparse Cholesky above 400 free vertices), 1 dense, 2 block-sparse.
+ * The reference uses g2o::BlockSolver_7_3 + LinearSolverEigen (sparse LDL^T, src/Optimizer.cpp:1072-1074); bchol_oracle.c restates that
+ * method on 7x7 blocks, the dense Cholesky is the same system factored without reordering (results agree to rounding). */
+static int g_ess_solver = 0;
+void orc_ess_set_solver(int mode) { g_ess_solver = mode; }
+
+/* sim3 [n][8] in/out; fixed[n]; edges (ei[k] = vertex 0, ej[k] = vertex 1, meas[k] = Sji).  Returns the iterations done; chi2 in out[0..1]. */
 int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale, int ne, const int32_t* ei, const int32_t* ej,
                         const double* meas, int iterations, double* chi2_out)
 {
@@ -1067,8 +1072,28 @@ int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale
     int nf = 0;
     for (int i = 0; i < n; i++) fidx[i] = fixed[i] ? -1 : nf++;
     const int N = 7 * nf;
-    double* H = (double*)calloc((size_t)(N > 0 ? N : 1) * (N > 0 ? N : 1), sizeof(double));
-    double* Hl = (double*)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1) * (N > 0 ? N : 1));
+    const int sparse = g_ess_solver == 2 || (g_ess_solver == 0 && nf > 400);
+    /* block-sparse form: slot[ia * nf + ib] (ia <= ib) -> 7x7 block of H in Hb, pattern = the edges */
+    int32_t* slot = NULL; double* Hb = NULL; double* Hbl = NULL; orc_bchol* chol = NULL; int nslot = 0;
+    if (sparse && nf > 0) {
+        slot = (int32_t*)malloc(sizeof(int32_t) * (size_t)nf * nf);
+        memset(slot, 0xff, sizeof(int32_t) * (size_t)nf * nf);
+        uint8_t* adj = (uint8_t*)calloc((size_t)nf * nf, 1);
+        for (int i = 0; i < nf; i++) slot[(size_t)i * nf + i] = nslot++;
+        for (int k = 0; k < ne; k++) {
+            const int ia = fidx[ei[k]], ib = fidx[ej[k]];
+            if (ia < 0 || ib < 0 || ia == ib) continue;
+            const int lo = ia < ib ? ia : ib, hi = ia < ib ? ib : ia;
+            if (slot[(size_t)lo * nf + hi] < 0) { slot[(size_t)lo * nf + hi] = nslot++; adj[(size_t)lo * nf + hi] = 1; }
+        }
+        chol = orc_bchol_new_bs(nf, adj, 7);
+        free(adj);
+        Hb = (double*)malloc(sizeof(double) * 49 * (size_t)nslot);
+        Hbl = (double*)malloc(sizeof(double) * 49 * (size_t)nslot);
+    }
+    const size_t NN = sparse ? 1 : (size_t)(N > 0 ? N : 1) * (N > 0 ? N : 1);
+    double* H = (double*)calloc(NN, sizeof(double));
+    double* Hl = (double*)malloc(sizeof(double) * NN);
     double* b = (double*)calloc(N > 0 ? N : 1, sizeof(double));
     double* x = (double*)calloc(N > 0 ? N : 1, sizeof(double));
     double* save = (double*)malloc(sizeof(double) * 8 * (size_t)(n > 0 ? n : 1));
@@ -1076,7 +1101,8 @@ int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale
     int nBad = 0, done = 0;
     double first_chi = -1, cur = 0;
     for (int it = 0; it < iterations && N > 0 && ne > 0; it++) {
-        memset(H, 0, sizeof(double) * (size_t)N * N); memset(b, 0, sizeof(double) * N);
+        if (sparse) memset(Hb, 0, sizeof(double) * 49 * (size_t)nslot); else memset(H, 0, sizeof(double) * (size_t)N * N);
+        memset(b, 0, sizeof(double) * N);
         cur = 0;
         for (int k = 0; k < ne; k++) {
             const double* C = meas + 8 * (size_t)k;
@@ -1107,10 +1133,12 @@ int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale
                 for (int vb = 0; vb < 2; vb++) {
                     const int ib = fidx[vb == 0 ? ei[k] : ej[k]];
                     if (ib < 0) continue;
+                    if (sparse && ia > ib) continue;                        /* upper blocks only */
+                    double* Hs = sparse ? Hb + 49 * (size_t)slot[(size_t)ia * nf + ib] : NULL;
                     for (int p = 0; p < 7; p++) for (int q = 0; q < 7; q++) {
                         double h = 0;
                         for (int r = 0; r < 7; r++) h += J[va][r * 7 + p] * J[vb][r * 7 + q];
-                        H[(size_t)(7 * ia + p) * N + 7 * ib + q] += h;
+                        if (sparse) Hs[p * 7 + q] += h; else H[(size_t)(7 * ia + p) * N + 7 * ib + q] += h;
                     }
                 }
             }
@@ -1121,12 +1149,20 @@ int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale
         double rho = 0; int qmax = 0;
         do {
             memcpy(save, sim3, sizeof(double) * 8 * (size_t)n);
-            memcpy(Hl, H, sizeof(double) * (size_t)N * N);
-            for (int j = 0; j < N; j++) Hl[(size_t)j * N + j] += lambda;
-            const int ok2 = chol_factor(Hl, N);
+            int ok2;
+            if (sparse) {
+                memcpy(Hbl, Hb, sizeof(double) * 49 * (size_t)nslot);
+                for (int i = 0; i < nf; i++) for (int d = 0; d < 7; d++) Hbl[49 * (size_t)slot[(size_t)i * nf + i] + 8 * d] += lambda;
+                ok2 = orc_bchol_factor(chol, slot, Hbl);
+            } else {
+                memcpy(Hl, H, sizeof(double) * (size_t)N * N);
+                for (int j = 0; j < N; j++) Hl[(size_t)j * N + j] += lambda;
+                ok2 = chol_factor(Hl, N);
+            }
             double temp = DBL_MAX;
             if (ok2) {
-                memcpy(x, b, sizeof(double) * N); chol_solve(Hl, N, x);
+                if (sparse) orc_bchol_solve(chol, b, x);
+                else { memcpy(x, b, sizeof(double) * N); chol_solve(Hl, N, x); }
                 for (int v = 0; v < n; v++) {
                     if (fidx[v] < 0) continue;
                     double o[8]; sim3_oplus(sim3 + 8 * (size_t)v, x + 7 * fidx[v], fix_scale, o);
@@ -1154,6 +1190,6 @@ int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale
         if (nBad >= 3) break;
     }
     if (chi2_out) { chi2_out[0] = first_chi < 0 ? 0 : first_chi; chi2_out[1] = cur; }
-    free(fidx); free(H); free(Hl); free(b); free(x); free(save);
+    free(fidx); free(H); free(Hl); free(b); free(x); free(save); free(slot); free(Hb); free(Hbl); orc_bchol_free(chol);
     return done;
 }

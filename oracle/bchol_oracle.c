@@ -20,6 +20,7 @@
 
 struct orc_bchol {
     int nb;
+    int bs;         /* block size: 6 (reduced camera system) or 7 (Sim3 pose graph) */
     int* perm;      /* step -> original block */
     int* iperm;     /* original block -> step */
     int* colptr;    /* [nb+1] into rowidx / L, strictly-lower blocks of permuted column k */
@@ -33,10 +34,11 @@ struct orc_bchol {
 
 static inline int popc64(unsigned long long v) { return __builtin_popcountll(v); }
 
-orc_bchol* orc_bchol_new(int nb, const uint8_t* adj /* nb*nb, non-zero where a block exists (any triangle) */)
+orc_bchol* orc_bchol_new_bs(int nb, const uint8_t* adj /* nb*nb, non-zero where a block exists (any triangle) */, int bs)
 {
     orc_bchol* c = (orc_bchol*)calloc(1, sizeof *c);
-    c->nb = nb;
+    c->nb = nb; c->bs = bs;
+    const int BS = bs, BB = bs * bs;
     const int W = (nb + 63) / 64;
     unsigned long long* A = (unsigned long long*)calloc((size_t)nb * W + 1, 8);
     for (int i = 0; i < nb; i++)
@@ -90,15 +92,17 @@ orc_bchol* orc_bchol_new(int nb, const uint8_t* adj /* nb*nb, non-zero where a b
         for (int a = 1; a < m; a++) { const int v = r[a]; int b = a - 1; while (b >= 0 && r[b] > v) { r[b + 1] = r[b]; b--; } r[b + 1] = v; }
         for (int a = 0; a < m; a++) c->pos[(size_t)r[a] * nb + k] = c->colptr[k] + a;
         c->colptr[k + 1] = c->colptr[k] + m;
-        fl += 2.0 * (36.0 * 6 / 6 + (double)m * 6 * 21 + (double)m * (m + 1) / 2 * 216);
+        fl += 2.0 * ((double)BB * BS / 6 + (double)m * BS * (BS * (BS + 1) / 2) + (double)m * (m + 1) / 2 * BB * BS);
         free(colrows[k]);
     }
     c->flops = fl;
-    c->D = (double*)malloc(sizeof(double) * 36 * (size_t)(nb + 1));
-    c->L = (double*)malloc(sizeof(double) * 36 * (size_t)(nnz + 1));
+    c->D = (double*)malloc(sizeof(double) * BB * (size_t)(nb + 1));
+    c->L = (double*)malloc(sizeof(double) * BB * (size_t)(nnz + 1));
     free(colrows); free(colcnt); free(nk); free(deg); free(alive); free(A);
     return c;
 }
+
+orc_bchol* orc_bchol_new(int nb, const uint8_t* adj) { return orc_bchol_new_bs(nb, adj, 6); }
 
 void orc_bchol_free(orc_bchol* c)
 {
@@ -109,19 +113,19 @@ void orc_bchol_free(orc_bchol* c)
 long orc_bchol_nnz(const orc_bchol* c) { return c->nnz; }
 double orc_bchol_flops(const orc_bchol* c) { return c->flops; }
 
-/* 6x6 lower Cholesky in place (row-major, upper part left untouched); 0 if not positive definite */
-static int chol6(double* A)
+/* BS x BS lower Cholesky in place (row-major, upper part left untouched); 0 if not positive definite */
+static int cholb(double* A, int BS)
 {
-    for (int j = 0; j < 6; j++) {
-        double d = A[j * 6 + j];
-        for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+    for (int j = 0; j < BS; j++) {
+        double d = A[j * BS + j];
+        for (int k = 0; k < j; k++) d -= A[j * BS + k] * A[j * BS + k];
         if (!(d > 0)) return 0;
-        d = sqrt(d); A[j * 6 + j] = d;
+        d = sqrt(d); A[j * BS + j] = d;
         const double id = 1.0 / d;
-        for (int i = j + 1; i < 6; i++) {
-            double v = A[i * 6 + j];
-            for (int k = 0; k < j; k++) v -= A[i * 6 + k] * A[j * 6 + k];
-            A[i * 6 + j] = v * id;
+        for (int i = j + 1; i < BS; i++) {
+            double v = A[i * BS + j];
+            for (int k = 0; k < j; k++) v -= A[i * BS + k] * A[j * BS + k];
+            A[i * BS + j] = v * id;
         }
     }
     return 1;
@@ -131,59 +135,59 @@ static int chol6(double* A)
  * blk[slot] = Hschur(f1, f2) row-major 6x6.  Returns 0 when a pivot block is not positive definite. */
 int orc_bchol_factor(orc_bchol* c, const int32_t* idx, const double* blk)
 {
-    const int nb = c->nb;
-    memset(c->D, 0, sizeof(double) * 36 * (size_t)nb);
-    memset(c->L, 0, sizeof(double) * 36 * (size_t)c->nnz);
+    const int nb = c->nb, BS = c->bs, BB = BS * BS;
+    memset(c->D, 0, sizeof(double) * BB * (size_t)nb);
+    memset(c->L, 0, sizeof(double) * BB * (size_t)c->nnz);
     for (int f1 = 0; f1 < nb; f1++)
         for (int f2 = f1; f2 < nb; f2++) {
             const int s = idx[(size_t)f1 * nb + f2];
             if (s < 0) continue;
-            const double* B = blk + 36 * (size_t)s;            /* block (f1, f2) */
+            const double* B = blk + BB * (size_t)s;            /* block (f1, f2) */
             const int p1 = c->iperm[f1], p2 = c->iperm[f2];
-            if (f1 == f2) { memcpy(c->D + 36 * (size_t)p1, B, 36 * sizeof(double)); continue; }
+            if (f1 == f2) { memcpy(c->D + BB * (size_t)p1, B, BB * sizeof(double)); continue; }
             if (p1 > p2) {                                      /* lower block (p1, p2) = B */
                 const int t = c->pos[(size_t)p1 * nb + p2];
                 if (t < 0) return -1;
-                memcpy(c->L + 36 * (size_t)t, B, 36 * sizeof(double));
+                memcpy(c->L + BB * (size_t)t, B, BB * sizeof(double));
             } else {                                            /* lower block (p2, p1) = B^T */
                 const int t = c->pos[(size_t)p2 * nb + p1];
                 if (t < 0) return -1;
-                double* T = c->L + 36 * (size_t)t;
-                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) T[i * 6 + j] = B[j * 6 + i];
+                double* T = c->L + BB * (size_t)t;
+                for (int i = 0; i < BS; i++) for (int j = 0; j < BS; j++) T[i * BS + j] = B[j * BS + i];
             }
         }
     for (int k = 0; k < nb; k++) {
-        double* Lkk = c->D + 36 * (size_t)k;
-        if (!chol6(Lkk)) return 0;
+        double* Lkk = c->D + BB * (size_t)k;
+        if (!cholb(Lkk, BS)) return 0;
         const int c0 = c->colptr[k], c1 = c->colptr[k + 1];
         for (int a = c0; a < c1; a++) {                         /* L_ik = A_ik Lkk^-T : forward substitution per row */
-            double* X = c->L + 36 * (size_t)a;
-            for (int r = 0; r < 6; r++)
-                for (int j = 0; j < 6; j++) {
-                    double v = X[r * 6 + j];
-                    for (int q = 0; q < j; q++) v -= X[r * 6 + q] * Lkk[j * 6 + q];
-                    X[r * 6 + j] = v / Lkk[j * 6 + j];
+            double* X = c->L + BB * (size_t)a;
+            for (int r = 0; r < BS; r++)
+                for (int j = 0; j < BS; j++) {
+                    double v = X[r * BS + j];
+                    for (int q = 0; q < j; q++) v -= X[r * BS + q] * Lkk[j * BS + q];
+                    X[r * BS + j] = v / Lkk[j * BS + j];
                 }
         }
         for (int a = c0; a < c1; a++) {
             const int i = c->rowidx[a];
-            const double* Li = c->L + 36 * (size_t)a;
-            double* Dii = c->D + 36 * (size_t)i;
-            for (int r = 0; r < 6; r++)
+            const double* Li = c->L + BB * (size_t)a;
+            double* Dii = c->D + BB * (size_t)i;
+            for (int r = 0; r < BS; r++)
                 for (int s2 = 0; s2 <= r; s2++) {
                     double v = 0;
-                    for (int q = 0; q < 6; q++) v += Li[r * 6 + q] * Li[s2 * 6 + q];
-                    Dii[r * 6 + s2] -= v;
+                    for (int q = 0; q < BS; q++) v += Li[r * BS + q] * Li[s2 * BS + q];
+                    Dii[r * BS + s2] -= v;
                 }
             const int* prow = c->pos + (size_t)i * nb;
             for (int b = c0; b < a; b++) {                      /* rows ascend: rowidx[b] < i */
-                const double* Lj = c->L + 36 * (size_t)b;
-                double* T = c->L + 36 * (size_t)prow[c->rowidx[b]];
-                for (int r = 0; r < 6; r++)
-                    for (int s2 = 0; s2 < 6; s2++) {
+                const double* Lj = c->L + BB * (size_t)b;
+                double* T = c->L + BB * (size_t)prow[c->rowidx[b]];
+                for (int r = 0; r < BS; r++)
+                    for (int s2 = 0; s2 < BS; s2++) {
                         double v = 0;
-                        for (int q = 0; q < 6; q++) v += Li[r * 6 + q] * Lj[s2 * 6 + q];
-                        T[r * 6 + s2] -= v;
+                        for (int q = 0; q < BS; q++) v += Li[r * BS + q] * Lj[s2 * BS + q];
+                        T[r * BS + s2] -= v;
                     }
             }
         }
@@ -191,30 +195,30 @@ int orc_bchol_factor(orc_bchol* c, const int32_t* idx, const double* blk)
     return 1;
 }
 
-/* x = Hschur^-1 b (original order, 6 nb doubles each) */
+/* x = Hschur^-1 b (original order, BS nb doubles each) */
 void orc_bchol_solve(const orc_bchol* c, const double* b, double* x)
 {
-    const int nb = c->nb;
-    double* y = (double*)malloc(sizeof(double) * 6 * (size_t)(nb + 1));
-    for (int k = 0; k < nb; k++) memcpy(y + 6 * k, b + 6 * (size_t)c->perm[k], 6 * sizeof(double));
+    const int nb = c->nb, BS = c->bs, BB = BS * BS;
+    double* y = (double*)malloc(sizeof(double) * BS * (size_t)(nb + 1));
+    for (int k = 0; k < nb; k++) memcpy(y + BS * k, b + BS * (size_t)c->perm[k], BS * sizeof(double));
     for (int k = 0; k < nb; k++) {                              /* L y' = y */
-        const double* Lkk = c->D + 36 * (size_t)k;
-        double* yk = y + 6 * k;
-        for (int j = 0; j < 6; j++) { double v = yk[j]; for (int q = 0; q < j; q++) v -= Lkk[j * 6 + q] * yk[q]; yk[j] = v / Lkk[j * 6 + j]; }
+        const double* Lkk = c->D + BB * (size_t)k;
+        double* yk = y + BS * k;
+        for (int j = 0; j < BS; j++) { double v = yk[j]; for (int q = 0; q < j; q++) v -= Lkk[j * BS + q] * yk[q]; yk[j] = v / Lkk[j * BS + j]; }
         for (int a = c->colptr[k]; a < c->colptr[k + 1]; a++) {
-            const double* Li = c->L + 36 * (size_t)a; double* yi = y + 6 * c->rowidx[a];
-            for (int r = 0; r < 6; r++) { double v = 0; for (int q = 0; q < 6; q++) v += Li[r * 6 + q] * yk[q]; yi[r] -= v; }
+            const double* Li = c->L + BB * (size_t)a; double* yi = y + BS * c->rowidx[a];
+            for (int r = 0; r < BS; r++) { double v = 0; for (int q = 0; q < BS; q++) v += Li[r * BS + q] * yk[q]; yi[r] -= v; }
         }
     }
     for (int k = nb - 1; k >= 0; k--) {                         /* L^T x' = y' */
-        const double* Lkk = c->D + 36 * (size_t)k;
-        double* yk = y + 6 * k;
+        const double* Lkk = c->D + BB * (size_t)k;
+        double* yk = y + BS * k;
         for (int a = c->colptr[k]; a < c->colptr[k + 1]; a++) {
-            const double* Li = c->L + 36 * (size_t)a; const double* yi = y + 6 * c->rowidx[a];
-            for (int q = 0; q < 6; q++) { double v = 0; for (int r = 0; r < 6; r++) v += Li[r * 6 + q] * yi[r]; yk[q] -= v; }
+            const double* Li = c->L + BB * (size_t)a; const double* yi = y + BS * c->rowidx[a];
+            for (int q = 0; q < BS; q++) { double v = 0; for (int r = 0; r < BS; r++) v += Li[r * BS + q] * yi[r]; yk[q] -= v; }
         }
-        for (int j = 5; j >= 0; j--) { double v = yk[j]; for (int q = j + 1; q < 6; q++) v -= Lkk[q * 6 + j] * yk[q]; yk[j] = v / Lkk[j * 6 + j]; }
+        for (int j = BS - 1; j >= 0; j--) { double v = yk[j]; for (int q = j + 1; q < BS; q++) v -= Lkk[q * BS + j] * yk[q]; yk[j] = v / Lkk[j * BS + j]; }
     }
-    for (int k = 0; k < nb; k++) memcpy(x + 6 * (size_t)c->perm[k], y + 6 * k, 6 * sizeof(double));
+    for (int k = 0; k < nb; k++) memcpy(x + BS * (size_t)c->perm[k], y + BS * k, BS * sizeof(double));
     free(y);
 }

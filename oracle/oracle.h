@@ -144,6 +144,7 @@ int  orc_ba_solve_once(const orc_ba_problem*, double huber_delta, double lambda,
 /* block-sparse Cholesky of the reduced camera system (bchol_oracle.c; linear_solver_eigen.h:106-136,165-222) */
 typedef struct orc_bchol orc_bchol;
 orc_bchol* orc_bchol_new(int nb, const uint8_t* adj);
+orc_bchol* orc_bchol_new_bs(int nb, const uint8_t* adj, int bs);   /* bs = 6 or 7 */
 void orc_bchol_free(orc_bchol*);
 long orc_bchol_nnz(const orc_bchol*);
 double orc_bchol_flops(const orc_bchol*);
@@ -159,6 +160,7 @@ void orc_sim3_exp(const double* update7, double* sim3);
 void orc_sim3_mul(const double* a, const double* b, double* o);
 void orc_sim3_inverse(const double* a, double* o);
 void orc_sim3_log(const double* sim3, double* log7);
+void orc_ess_set_solver(int mode);      /* 0 automatic (block-sparse above 400 free vertices), 1 dense, 2 block-sparse */
 int orc_essential_graph(int n, double* sim3, const uint8_t* fixed, int fix_scale, int ne, const int32_t* ei, const int32_t* ej,
                         const double* meas, int iterations, double* chi2_out);
 int orc_optimize_sim3(double* sim3, int fix_scale, const double* K1, const double* K2, int n, const double* P1, const double* P2,

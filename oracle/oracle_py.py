@@ -383,6 +383,11 @@ def essential_graph(sim3, fixed, edge_i, edge_j, meas, fix_scale=False, iteratio
     return s, dict(iterations_done=done, chi2_initial=chi[0], chi2_final=chi[1])
 
 
+def ess_set_solver(mode: int):
+    """Essential graph: 0 automatic (block-sparse Cholesky above 400 free vertices), 1 dense Cholesky, 2 block-sparse Cholesky."""
+    lib().orc_ess_set_solver(int(mode))
+
+
 def ba_set_solver(mode: int):
     """0 automatic (block-sparse Cholesky above 400 free keyframes), 1 dense Cholesky, 2 block-sparse Cholesky."""
     lib().orc_ba_set_solver(int(mode))

@@ -287,3 +287,21 @@ def test_gba_config5_golden_is_the_full_size_run():
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gba_config5.npz"))
     assert z["poses"].shape == (2000, 7) and int(z["n_edges"]) > 1_500_000 and list(z["iterations"]) == [5, 5]
     assert float(z["lin_check"][1]) < 1e-9 and z["chi2"][1] < 0.1 * z["chi2"][0]
+
+
+def test_essential_graph_block_sparse_solver_equals_dense(oracle):
+    """The oracle's two solvers of the pose graph's normal equations (dense Cholesky, block-sparse Cholesky on 7x7 blocks with a
+    minimum-degree order -- the reference's method, src/Optimizer.cpp:1072-1074) take the same LM path and agree to rounding on a
+    well-conditioned graph; the 2000-keyframe comparison of the GPU path (tests/test_sim3_gpu.py) rests on the sparse one."""
+    from sim3_problems import make_pose_graph
+    O = oracle
+    rng = np.random.default_rng(3)
+    sim3, fixed, ei, ej, meas, truth = make_pose_graph(O, rng, n=150, drift=0.002, scale_drift=0.0005, covis=3)
+    try:
+        O.ess_set_solver(1); a, ra = O.essential_graph(sim3, fixed, ei, ej, meas, iterations=20)
+        O.ess_set_solver(2); b, rb = O.essential_graph(sim3, fixed, ei, ej, meas, iterations=20)
+    finally:
+        O.ess_set_solver(0)
+    assert ra["iterations_done"] == rb["iterations_done"] >= 2
+    assert np.isclose(ra["chi2_final"], rb["chi2_final"], rtol=1e-9)
+    assert np.abs(a - b).max() < 1e-10

@@ -81,14 +81,19 @@ def test_essential_graph_matches_oracle(ctx, oracle, n, fix_scale):
         assert np.abs(moved[i] - exp).max() < 1e-12
 
 
-def test_essential_graph_2000_keyframes_properties(ctx, oracle):
-    """BASELINE's map size (2000 keyframes): too slow for the dense CPU oracle, so size-independent properties: the
-    error drops, the fixed keyframe stays, the loop keyframe pair agrees with the loop measurement afterwards."""
+def test_essential_graph_2000_keyframes(ctx, oracle):
+    """BASELINE's map size (2000 keyframes) against the oracle's block-sparse Cholesky (bchol_oracle.c on 7x7 blocks; the dense
+    oracle would need minutes), plus size-independent properties: the error drops, the fixed keyframe stays, the loop keyframe
+    pair agrees with the loop measurement afterwards."""
     from sim3_problems import make_pose_graph
     rng = np.random.default_rng(9)
     sim3, fixed, ei, ej, meas, truth = make_pose_graph(oracle, rng, n=2000, drift=0.002, scale_drift=0.0005, covis=3)
     out, info = Optimizer.OptimizeEssentialGraph(sim3, fixed, ei, ej, meas, False, 20, ctx=ctx)
     assert info["chi2_final"] < 0.05 * info["chi2_initial"] and (out[0] == sim3[0]).all()
+    ref, rinfo = oracle.essential_graph(sim3, fixed, ei, ej, meas, False, 20)                   # > 400 free vertices: block-sparse
+    assert info["iterations_done"] == rinfo["iterations_done"]
+    assert np.isclose(info["chi2_initial"], rinfo["chi2_initial"], rtol=1e-9) and np.isclose(info["chi2_final"], rinfo["chi2_final"], rtol=1e-6)
+    assert np.abs(out - ref).max() < 1e-6, np.abs(out - ref).max()
     # block-sparse solve (src/Optimizer.cpp:1072-1074: BlockSolver_7_3 + sparse Cholesky): no dense 13,993^2 matrix (1.57 GB) any more
     assert info["solver_bytes"] < 100e6 and info["factor_blocks"] >= 1999 + len(ei) - 8 and 0 < info["factor_rounds"] < 400, info
     again, info2 = Optimizer.OptimizeEssentialGraph(sim3, fixed, ei, ej, meas, False, 20, ctx=ctx)

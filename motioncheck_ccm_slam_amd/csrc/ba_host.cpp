@@ -220,8 +220,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // arrives sorted already, which one pass detects; otherwise a stable counting sort by landmark and an insertion sort of each
     // landmark's handful of observations by keyframe give the same order in linear time)
     std::vector<int> perm;
-    perm.reserve(Eall / ranks + 16);
     bool sorted = true;
+    int n_local = 0;
     {
         int prev_l = -1, prev_p = -1;
         for (int e = 0; e < Eall; e++) {
@@ -230,8 +230,14 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
             const int p = pb->edge_pose[e];
             if (l < prev_l || (l == prev_l && p < prev_p)) sorted = false;
             prev_l = l; prev_p = p;
-            perm.push_back(e);
+            n_local++;
         }
+    }
+    // a sorted, unsharded edge list is used where it lies (no index vector, no staging copies: 6 ms at config 5)
+    const bool direct = sorted && n_local == Eall && l0 == 0;
+    if (!direct) {
+        perm.reserve(n_local);
+        for (int e = 0; e < Eall; e++) { const int l = pb->edge_point[e]; if (l >= l0 && l < l1) perm.push_back(e); }
     }
     if (!sorted) {
         std::vector<int> first(L + 2, 0), out(perm.size());
@@ -250,14 +256,12 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
             }
         perm.swap(out);
     }
-    const int E = (int)perm.size();
+    const int E = n_local;
     // Per-phase timers need a stream synchronisation at every phase boundary.  On a large graph that costs nothing next to the phases; on a
     // local BA (tens of keyframes, launch-bound) the four extra round trips per LM trial were a quarter of the call, so small problems
     // skip them: their timers still add up to the wall time, but a phase's GPU time is booked where the next necessary sync happens.
     static const bool force_timers = getenv("CCM_BA_TIMERS") && atoi(getenv("CCM_BA_TIMERS")) != 0;
     const bool fine_timers = force_timers || E >= 200000;
-    // a sorted, unsharded edge list is used where it lies (no staging copies: another 5 ms at config 5)
-    const bool direct = sorted && E == Eall && l0 == 0;
     std::vector<int> e_pose_v, e_pt_v, pt_first(L + 1, 0);
     std::vector<double> e_obs_v, e_info_v;
     if (!direct) {
@@ -272,10 +276,13 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     const int32_t* e_pt = direct ? pb->edge_point : e_pt_v.data();
     const double* e_obs = direct ? pb->obs : e_obs_v.data();
     const double* e_info = direct ? pb->info : e_info_v.data();
-    for (int k = 0; k < E; k++) pt_first[e_pt[k] + 1]++;
-    for (int l = 0; l < L; l++) pt_first[l + 1] += pt_first[l];
     std::vector<int> pose_first(nfree + 1, 0), pose_edges;
-    for (int k = 0; k < E; k++) if (free_of[e_pose[k]] >= 0) pose_first[free_of[e_pose[k]] + 1]++;
+    for (int k = 0; k < E; k++) {
+        pt_first[e_pt[k] + 1]++;
+        const int f = free_of[e_pose[k]];
+        if (f >= 0) pose_first[f + 1]++;
+    }
+    for (int l = 0; l < L; l++) pt_first[l + 1] += pt_first[l];
     for (int f = 0; f < nfree; f++) pose_first[f + 1] += pose_first[f];
     pose_edges.resize(pose_first[nfree]);
     {
@@ -720,11 +727,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         }
         CCM_HIP(c, hipStreamSynchronize(st));
         if (ranks == 1) {
-            for (int k = 0; k < E; k++) outlier_out[perm[k]] = fl[k];
+            for (int k = 0; k < E; k++) outlier_out[direct ? k : perm[k]] = fl[k];
         } else {
             // flags of the other ranks' edges: exchange as doubles through the same collective
             std::vector<double> full(Eall, 0.0);
-            for (int k = 0; k < E; k++) full[perm[k]] = fl[k];
+            for (int k = 0; k < E; k++) full[direct ? k : perm[k]] = fl[k];
             CCM_RESERVE(c, S.gather, std::max<size_t>((size_t)Eall * 8, 16));
             CCM_HIP(c, hipMemcpyAsync(S.gather.p, full.data(), (size_t)Eall * 8, hipMemcpyHostToDevice, st));
             if ((rc = comm_allreduce_f64(c, S.gather.as<double>(), Eall, false))) return rc;

@@ -536,6 +536,12 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 CCM_HIP(c, hipMemcpyAsync(S.save_poses.p, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));   // push
                 if (L) CCM_HIP(c, hipMemcpyAsync(S.save_points.p, D.points, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
                 int ok2 = 1;
+                // The dense solve's verdict ("not positive definite") of a small, single-rank problem is read together with the
+                // trial's chi2 instead of in a round trip of its own (a local BA is launch- and round-trip-bound: three host syncs
+                // per trial were a fifth of the call): the trial's update is applied as if the solve had succeeded and, if it had
+                // not, discarded exactly like a rejected step (the saved poses and points come back).
+                volatile int* dense_info = reinterpret_cast<volatile int*>(S.pinned + 14);   // pinned: a copy to pageable memory would synchronise
+                bool dense_info_pending = false;
                 auto t2 = t1;
                 if (nfree > 0) {
                     { ProfScope ps(c, CCM_PROF_BA_DINV_Y); sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>()); }
@@ -643,10 +649,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         sp_launch_to_dense(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, (long long)npd, Hs);   // row-major upper block triangle, pitch npd
                         dense_launch_solve(st, Hs, (int)n, (int)npd, D.bs, D.x, info_dev);
                         }
-                        int info = 0;
-                        CCM_HIP(c, hipMemcpyAsync(&info, info_dev, 4, hipMemcpyDeviceToHost, st));
-                        CCM_HIP(c, hipStreamSynchronize(st));
-                        ok2 = info == 0;
+                        CCM_HIP(c, hipMemcpyAsync(S.pinned + 14, info_dev, 4, hipMemcpyDeviceToHost, st));
+                        if (ranks == 1 && !fine_timers) dense_info_pending = true;
+                        else { CCM_HIP(c, hipStreamSynchronize(st)); ok2 = *dense_info == 0; }
                     }
                     if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
                 } else {
@@ -678,7 +683,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 if (ok2) {
                     if (L > 0) { ProfScope ps(c, CCM_PROF_BA_BACKSUB); ba_launch_backsub(st, D); }
                     ba_launch_update(st, D);
-                    if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale))) return rc;
+                    if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale))) return rc;     // synchronises the stream
+                    if (dense_info_pending && *dense_info != 0) { ok2 = 0; tempChi = DBL_MAX; scale = 0; }
                 }
                 scale += 1e-3;
                 rho = ok2 ? (currentChi - tempChi) / scale : -1.0;

@@ -932,23 +932,25 @@ void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc, cons
     hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nblk(6LL * nfree, PCG_UPD_TPB), part, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
 }
 
-// Reduced systems of a local BA (config 4: 20 free keyframes, n = 120 unknowns) are solved by ONE workgroup inside LDS: the upper
-// blocks are scattered into a dense lower triangle, factored L L^T column by column (two barriers per column), and the two
-// triangular solves follow in the same launch.  The block Gauss-Jordan path below needs ~14 launches for such a system and took
-// 0.5 ms per LM trial -- 70 % of the whole local BA; this takes one.  n <= DENSE_SMALL_MAX so that n^2 + n doubles fit the CU's LDS.
+// Reduced systems of a local BA (config 4: 20 free keyframes, n = 120 unknowns) are solved by ONE workgroup in one launch: L L^T
+// factorisation and both triangular solves.  The block Gauss-Jordan path below needs ~14 launches for such a system and took
+// 0.5 ms per LM trial -- 70 % of the whole local BA.  n <= DENSE_SMALL_MAX so that every tile of the lower triangle has its thread.
 #define DENSE_SMALL_MAX 138
 #define DS_TPB 320
-// Every 6x6 tile of the lower triangle lives in the REGISTERS of one thread for the whole factorisation (n <= 138: at most 276 tiles):
-// per block column the diagonal tile's owner factors it and publishes it in LDS, the owners of the tiles below solve against it and
-// publish the panel, every remaining tile subtracts panel_I panel_K^T from its registers -- two barriers per block column, and the only
-// LDS traffic is the panel.  (The same algorithm with the matrix in LDS took 133 us at n = 120, column by column 256 us.)
+// Every 6x6 tile of the lower triangle lives in the REGISTERS of one thread for the whole solve (n <= 138: at most 276 tiles):
+// per block column the diagonal tile's owner factors it and publishes it in LDS, the owners of the tiles below solve against it
+// (multiplying by the reciprocals of its diagonal: a double-precision division is ~12 instructions, 36 of them per tile and column
+// were a fifth of the kernel) and publish the panel, every remaining tile subtracts panel_I panel_K^T from its registers -- two
+// barriers per block column, and the only LDS traffic is the panel and the right-hand side.  The forward substitution rides along
+// with the factorisation and the backward one reads the factor from the registers it already is in, so the factor is never written
+// anywhere.  (History at n = 120: matrix in LDS column by column 256 us, blocked in LDS 133 us, register tiles + the factor copied
+// to LDS for two separate substitution loops 116 us.)
 __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __restrict__ Hb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                                               int nb, int n, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ bad)
 {
     extern __shared__ double ds_lds[];
-    double* A = ds_lds;                      // [n][n]: the factor for the triangular solves (lower triangle)
-    double* v = ds_lds + (size_t)n * n;      // [n] right-hand side / solution
-    __shared__ double s_ljj[36];
+    double* v = ds_lds;                      // [n] right-hand side -> y -> solution
+    __shared__ double s_ljj[36], s_linv[6], s_y[6];
     __shared__ double s_panel[DENSE_SMALL_MAX / 6][36];
     __shared__ int s_tile_blk[DENSE_SMALL_MAX / 6 * (DENSE_SMALL_MAX / 6 + 1) / 2];
     __shared__ int s_bad;
@@ -982,7 +984,12 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
                 for (int k = 0; k < i; k++) T[i][k] = T[k][i];
         }
     }
+    double dinv[6] = { 0, 0, 0, 0, 0, 0 };                                   // a diagonal tile's owner: 1 / L_cc
+    // factorisation, with the forward substitution L y = b riding along: the diagonal tile's owner solves its six unknowns as soon
+    // as the tile is factored, and the owner of panel tile (I, J) takes its product with y_J off b_I when the tile is final
+    // (one writer per block row and step).  Two barriers per block column.
     for (int J = 0; J < nbk; J++) {
+        const int j0 = 6 * J;
         if (have && I == J && K == J) {                                      // 6x6 Cholesky of the diagonal tile
 #pragma unroll
             for (int c = 0; c < 6; c++) {
@@ -992,6 +999,7 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
                 if (!(d > 0.0)) { s_bad = 1; d = 1.0; }
                 d = sqrt(d); T[c][c] = d;
                 const double id = 1.0 / d;
+                dinv[c] = id;
 #pragma unroll
                 for (int r = c + 1; r < 6; r++) {
                     double w = T[r][c];
@@ -1000,18 +1008,30 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
                     T[r][c] = w * id;
                 }
             }
+            double y[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++)
+            for (int c = 0; c < 6; c++) {
+                double w = v[j0 + c];
+#pragma unroll
+                for (int k = 0; k < c; k++) w -= T[c][k] * y[k];
+                y[c] = w * dinv[c];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) { if (k > i) T[i][k] = 0.0; s_ljj[i * 6 + k] = T[i][k]; }
+                s_linv[i] = dinv[i]; s_y[i] = y[i]; v[j0 + i] = y[i];
+            }
         }
         __syncthreads();
         if (have && K == J && I > J) {                                       // panel tile: X L_JJ^T = T, row by row
-            double lj[6][6];
+            double lj[6][6], li[6], yj[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++)
+            for (int i = 0; i < 6; i++) {
+                li[i] = s_linv[i]; yj[i] = s_y[i];
 #pragma unroll
-                for (int k = 0; k <= i; k++) lj[i][k] = s_ljj[i * 6 + k];
+                for (int k = 0; k < i; k++) lj[i][k] = s_ljj[i * 6 + k];
+            }
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -1019,12 +1039,14 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
                     double w = T[r][c];
 #pragma unroll
                     for (int k = 0; k < c; k++) w -= T[r][k] * lj[c][k];
-                    T[r][c] = w / lj[c][c];
+                    T[r][c] = w * li[c];
                 }
 #pragma unroll
-            for (int i = 0; i < 6; i++)
+            for (int i = 0; i < 6; i++) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) s_panel[I][i * 6 + k] = T[i][k];
+                v[6 * I + i] -= ((T[i][0] * yj[0] + T[i][1] * yj[1]) + (T[i][2] * yj[2] + T[i][3] * yj[3])) + (T[i][4] * yj[4] + T[i][5] * yj[5]);
+            }
         }
         __syncthreads();
         if (have && K > J) {                                                 // trailing tile: T -= panel_I panel_K^T
@@ -1044,66 +1066,31 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
                 }
         }
     }
-    if (have) {                                                              // the factor to LDS for the two triangular solves
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int k = 0; k < 6; k++) A[(6 * I + i) * n + 6 * K + k] = T[i][k];
-    }
     __syncthreads();
-    for (int J = 0; J < nbk; J++) {                                          // L y = b, block column by block column
+    // L^T x = y from the tiles where they are (registers): block row J of L is what column J of L^T needs
+    for (int J = nbk - 1; J >= 0; J--) {
         const int j0 = 6 * J;
-        if (tid == 0) {
-            double lj[6][6], y[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                y[c] = v[j0 + c];
-#pragma unroll
-                for (int k = 0; k <= c; k++) lj[c][k] = A[(j0 + c) * n + j0 + k];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double w = y[c];
-#pragma unroll
-                for (int k = 0; k < c; k++) w -= lj[c][k] * y[k];
-                y[c] = w / lj[c][c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++) v[j0 + c] = y[c];
-        }
-        __syncthreads();
-        for (int i = j0 + 6 + tid; i < n; i += DS_TPB) {
-            const double* li = A + i * n + j0;
-            v[i] -= ((li[0] * v[j0] + li[1] * v[j0 + 1]) + (li[2] * v[j0 + 2] + li[3] * v[j0 + 3])) + (li[4] * v[j0 + 4] + li[5] * v[j0 + 5]);
-        }
-        __syncthreads();
-    }
-    for (int J = nbk - 1; J >= 0; J--) {                                     // L^T x = y  (a single-wave form of the two solves, vector in
-        const int j0 = 6 * J;                                                // registers and no barriers, measured slower: 36 us more per call)
-        if (tid == 0) {
-            double lj[6][6], y[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                y[c] = v[j0 + c];
-#pragma unroll
-                for (int k = 0; k <= c; k++) lj[c][k] = A[(j0 + c) * n + j0 + k];
-            }
+        if (have && I == J && K == J) {
+            double xx[6];
 #pragma unroll
             for (int c = 5; c >= 0; c--) {
-                double w = y[c];
+                double w = v[j0 + c];
 #pragma unroll
-                for (int k = c + 1; k < 6; k++) w -= lj[k][c] * y[k];
-                y[c] = w / lj[c][c];
+                for (int k = c + 1; k < 6; k++) w -= T[k][c] * xx[k];
+                xx[c] = w * dinv[c];
             }
 #pragma unroll
-            for (int c = 0; c < 6; c++) v[j0 + c] = y[c];
+            for (int c = 0; c < 6; c++) { v[j0 + c] = xx[c]; s_y[c] = xx[c]; }
         }
         __syncthreads();
-        for (int i = tid; i < j0; i += DS_TPB) {
-            double w = 0;
+        if (have && I == J && K < J) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) w += A[(j0 + c) * n + i] * v[j0 + c];
-            v[i] -= w;
+            for (int c = 0; c < 6; c++) {
+                double w = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) w += T[r][c] * s_y[r];
+                v[6 * K + c] -= w;
+            }
         }
         __syncthreads();
     }
@@ -1113,7 +1100,7 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
 int dense_small_max() { return DENSE_SMALL_MAX; }
 int dense_launch_small_solve(hipStream_t s, const double* Hb, const int* blk_row, const int* blk_col, int nb, int n, const double* b, double* x, int* bad)
 {
-    const size_t lds = ((size_t)n * n + n) * sizeof(double);
+    const size_t lds = (size_t)(n + 8) * sizeof(double);
     if (hipFuncSetAttribute((const void*)k_dense_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     hipLaunchKernelGGL(k_dense_small_solve, dim3(1), dim3(DS_TPB), lds, s, Hb, blk_row, blk_col, nb, n, b, x, bad);
     return 0;

@@ -239,10 +239,11 @@ def test_search_for_triangulation(ctx, oracle):
 
 def test_device_acceptance_chains_and_large_batches(ctx, oracle):
     """The order-dependent acceptance on the device (k_window_greedy) at its corners:
-    (a) 3000 map points projected into ONE small region: every point competes with every earlier one, so the claim rounds
-        resolve one point at a time and the kernel's sequential tail (after 48 rounds) takes over;
-    (b) 20,000 map points against one keyframe (server-side map matching): no candidate list leaves the GPU.
-    Both must equal the reference's sequential loop (the oracle) exactly, for SearchByProjection(Frame, points) and for
+    (a) 3000 map points projected into ONE small region: every point competes with every earlier one, so the workgroup-wide claim
+        rounds decide little and the waves finish their points in order, round by round;
+    (b) 20,000 map points against one keyframe (server-side map matching): no candidate list leaves the GPU;
+    (c) wide windows: more candidates per point than the 16 a thread keeps in registers.
+    All must equal the reference's sequential loop (the oracle) exactly, for SearchByProjection(Frame, points) and for
     SearchByProjection(KF, Scw)."""
     fr, sf, kps, desc = _frame(ctx, 10)
     n = len(fr.kx)
@@ -283,6 +284,22 @@ def test_device_acceptance_chains_and_large_batches(ctx, oracle):
     bi, bd = m.FuseSelect(fr, sf, is2, valid, px, py, level, mp_desc, 3.0, True)
     rbi, rbd = oracle.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, valid, px, py, level, mp_desc, 3.0, True)
     assert (bi == rbi).all() and (bd == rbd).all() and (bi >= 0).sum() > 5000
+    # (c) wide windows
+    nmp = 1500
+    src = rng.integers(0, n, nmp)
+    mp_desc = desc[src] ^ np.packbits(rng.random((nmp, 256)) < 0.08, axis=1, bitorder="little")
+    px = (fr.kx[src] + rng.normal(0, 4.0, nmp)).astype("f4"); py = (fr.ky[src] + rng.normal(0, 4.0, nmp)).astype("f4")
+    level = np.clip(fr.oct[src] + rng.integers(0, 2, nmp), 0, 7)
+    ones = np.ones(nmp, bool); has_obs = rng.random(nmp) < 0.8; observed = rng.random(nmp) < 0.2
+    cn = m.FeaturesInArea(fr, px, py, (25.0 * np.asarray(sf)[level]).astype("f4"), (level - 1).astype("i4"), level.astype("i4"), mp_desc, cap=256)[2]
+    assert (cn > 16).sum() > 100, (cn > 16).sum()
+    nm, match, occ = m.SearchByProjection(fr, sf, ones, level, np.full(nmp, 0.9, "f4"), px, py, mp_desc, has_obs, occ0, 25.0 / 4.0)
+    rn, rmatch, rocc = oracle.search_by_projection(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, ones, level,
+                                                   np.full(nmp, 0.9, "f4"), px, py, mp_desc, has_obs, occ0, 25.0 / 4.0, 0.8)
+    assert nm == rn and (match == rmatch).all() and (occ == rocc).all() and nm > 100
+    n2, bi, mt = m.SearchByProjectionSim3(fr, sf, ones, px, py, level, mp_desc, observed, occ0, 25.0)
+    r2, rbi, rmt = oracle.search_by_projection_sim3(fr, sf, ones, px, py, level, mp_desc, observed, occ0, 25.0)
+    assert n2 == r2 and (bi == rbi).all() and (mt == rmt).all() and n2 > 100
 
 
 def test_host_acceptance_paths_stay_exact():

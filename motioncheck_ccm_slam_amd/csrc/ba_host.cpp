@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <chrono>
 #include <numeric>
+#include <thread>
 
 int comm_ranks(const ccm_ctx* c);
 int comm_rank(const ccm_ctx* c);
@@ -219,18 +220,43 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // (a comparison sort of the 1.8 M edges of config 5 took 20 ms, a fifth of the whole call: a graph extracted landmark by landmark
     // arrives sorted already, which one pass detects; otherwise a stable counting sort by landmark and an insertion sort of each
     // landmark's handful of observations by keyframe give the same order in linear time)
+    // The passes over the edge list below were 4 ms of host time at config 5 (1.8 M edges): large graphs deal them to a few threads
+    // (contiguous slices; every result is the same as the serial loop's).
+    const int NT = Eall >= 400000 ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    auto pfor = [&](auto&& fn) {
+        if (NT == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < NT; t++) th.emplace_back([&fn, t]() { fn(t); });
+        fn(0);
+        for (auto& x : th) x.join();
+    };
+    auto slice = [&](long long total, int t) { return std::pair<long long, long long>(total * t / NT, total * (t + 1) / NT); };
     std::vector<int> perm;
     bool sorted = true;
     int n_local = 0;
     {
-        int prev_l = -1, prev_p = -1;
-        for (int e = 0; e < Eall; e++) {
-            const int l = pb->edge_point[e];
-            if (l < l0 || l >= l1) continue;
-            const int p = pb->edge_pose[e];
-            if (l < prev_l || (l == prev_l && p < prev_p)) sorted = false;
-            prev_l = l; prev_p = p;
-            n_local++;
+        std::vector<int> cnt(NT, 0), bad(NT, 0), first_l(NT, -1), first_p(NT, -1), last_l(NT, -1), last_p(NT, -1);
+        pfor([&](int t) {
+            const auto r = slice(Eall, t);
+            int prev_l = -1, prev_p = -1, c = 0, b = 0;
+            for (long long e = r.first; e < r.second; e++) {
+                const int l = pb->edge_point[e];
+                if (l < l0 || l >= l1) continue;
+                const int p = pb->edge_pose[e];
+                if (c == 0) { first_l[t] = l; first_p[t] = p; }
+                else if (l < prev_l || (l == prev_l && p < prev_p)) b = 1;
+                prev_l = l; prev_p = p; c++;
+            }
+            cnt[t] = c; bad[t] = b; last_l[t] = prev_l; last_p[t] = prev_p;
+        });
+        int pl = -1, pp = -1;
+        for (int t = 0; t < NT; t++) {
+            if (bad[t]) sorted = false;
+            if (cnt[t]) {
+                if (first_l[t] < pl || (first_l[t] == pl && first_p[t] < pp)) sorted = false;      // across the slice boundary
+                pl = last_l[t]; pp = last_p[t];
+            }
+            n_local += cnt[t];
         }
     }
     // a sorted, unsharded edge list is used where it lies (no index vector, no staging copies: 6 ms at config 5)
@@ -276,18 +302,37 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     const int32_t* e_pt = direct ? pb->edge_point : e_pt_v.data();
     const double* e_obs = direct ? pb->obs : e_obs_v.data();
     const double* e_info = direct ? pb->info : e_info_v.data();
+    // pt_first: the edges are sorted by landmark, so a landmark's first edge is where the landmark index changes;
+    // pose_edges: stable counting sort of the edges by free keyframe, slice by slice
     std::vector<int> pose_first(nfree + 1, 0), pose_edges;
-    for (int k = 0; k < E; k++) {
-        pt_first[e_pt[k] + 1]++;
-        const int f = free_of[e_pose[k]];
-        if (f >= 0) pose_first[f + 1]++;
-    }
-    for (int l = 0; l < L; l++) pt_first[l + 1] += pt_first[l];
-    for (int f = 0; f < nfree; f++) pose_first[f + 1] += pose_first[f];
-    pose_edges.resize(pose_first[nfree]);
     {
-        std::vector<int> fill(pose_first.begin(), pose_first.end() - 1);
-        for (int k = 0; k < E; k++) { const int f = free_of[e_pose[k]]; if (f >= 0) pose_edges[fill[f]++] = k; }
+        std::vector<std::vector<int>> hist(NT, std::vector<int>(nfree + 1, 0));
+        pfor([&](int t) {
+            const auto r = slice(E, t);
+            std::vector<int>& h = hist[t];
+            for (long long k = r.first; k < r.second; k++) {
+                const int l = e_pt[k];
+                const int lp = k > 0 ? e_pt[k - 1] : -1;
+                for (int q = lp + 1; q <= l; q++) pt_first[q] = (int)k;           // landmarks without edges in between start here too
+                const int f = free_of[e_pose[k]];
+                if (f >= 0) h[f]++;
+            }
+        });
+        const int last = E > 0 ? e_pt[E - 1] : -1;
+        for (int q = last + 1; q <= L; q++) pt_first[q] = E;
+        // slice t's first slot for keyframe f = all earlier keyframes + f's edges in earlier slices
+        int acc = 0;
+        for (int f = 0; f < nfree; f++) {
+            pose_first[f] = acc;
+            for (int t = 0; t < NT; t++) { const int c = hist[t][f]; hist[t][f] = acc; acc += c; }
+        }
+        pose_first[nfree] = acc;
+        pose_edges.resize(acc);
+        pfor([&](int t) {
+            const auto r = slice(E, t);
+            std::vector<int>& fill = hist[t];
+            for (long long k = r.first; k < r.second; k++) { const int f = free_of[e_pose[k]]; if (f >= 0) pose_edges[fill[f]++] = (int)k; }
+        });
     }
 
     lap("host: sort + index edges");

@@ -71,14 +71,27 @@ __global__ __launch_bounds__(256) void k_ba_reduce(const double* __restrict__ in
 }
 
 // One thread per landmark: accumulate Hll (full 3x3) and b_l over its edges, store Hpl = w B^T A per edge.
+// G lanes per landmark: 1 on large maps (a thread walks its landmark's edges: no reduction, the sums in edge order), 8 on small ones --
+// a local BA has 5000 landmarks, i.e. 79 waves on a chip with room for 8192, and a thread's walk over eight edges was eight
+// dependent rounds of f64 latency; the eight partial sums are added pairwise by xor-shuffles (a fixed tree: reproducible).
+template <int G>
+__device__ __forceinline__ double ba_group_sum(double v)
+{
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+template <int G>
 __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_delta)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= D.L) return;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int l = gt / G, g = gt - l * G;
+    const bool live = l < D.L;
     double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, b[3] = { 0, 0, 0 };
-    const double* pt = D.points + 3 * (long long)l;
+    const double* pt = D.points + 3 * (long long)(live ? l : 0);
     const double p3[3] = { pt[0], pt[1], pt[2] };
-    for (int e = D.pt_first[l]; e < D.pt_first[l + 1]; e++) {
+    const int e0 = live ? D.pt_first[l] : 0, e1 = live ? D.pt_first[l + 1] : 0;
+    for (int e = e0 + g; e < e1; e += G) {
         double* Hx = D.Hpl + 18 * (long long)e;
         if (!D.active[e]) { for (int i = 0; i < 18; i++) Hx[i] = 0; continue; }
         const int pi = D.edge_pose[e];
@@ -97,8 +110,16 @@ __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_d
         for (int i = 0; i < 6; i++)
             for (int j = 0; j < 3; j++) Hx[i * 3 + j] = fr ? w * (B[i] * A[j] + B[6 + i] * A[3 + j]) : 0.0;
     }
-    for (int i = 0; i < 9; i++) D.Hll[9 * (long long)l + i] = H[i];
-    for (int i = 0; i < 3; i++) D.bl[3 * (long long)l + i] = b[i];
+    if (G > 1) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) H[i] = ba_group_sum<G>(H[i]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) b[i] = ba_group_sum<G>(b[i]);
+    }
+    if (live && g == 0) {
+        for (int i = 0; i < 9; i++) D.Hll[9 * (long long)l + i] = H[i];
+        for (int i = 0; i < 3; i++) D.bl[3 * (long long)l + i] = b[i];
+    }
 }
 
 // One workgroup (4 waves) per free pose: the waves take every fourth 64-edge run of the pose's list, reduce inside the wave by a fixed
@@ -190,18 +211,25 @@ __global__ __launch_bounds__(256) void k_ba_lin_pose_wave(BaDev D, double huber_
     }
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev D)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= D.L) return;
-    double c0 = D.bl[3 * (long long)l], c1 = D.bl[3 * (long long)l + 1], c2 = D.bl[3 * (long long)l + 2];
-    for (int e = D.pt_first[l]; e < D.pt_first[l + 1]; e++) {
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int l = gt / G, g = gt - l * G;
+    const bool live = l < D.L;
+    const long long ll = live ? l : 0;
+    double c0 = 0, c1 = 0, c2 = 0;
+    if (g == 0) { c0 = D.bl[3 * ll]; c1 = D.bl[3 * ll + 1]; c2 = D.bl[3 * ll + 2]; }
+    const int e0 = live ? D.pt_first[l] : 0, e1 = live ? D.pt_first[l + 1] : 0;
+    for (int e = e0 + g; e < e1; e += G) {
         const int f = D.free_of[D.edge_pose[e]];
         if (f < 0 || !D.active[e]) continue;
         const double* Bi = D.Hpl + 18 * (long long)e;
         const double* xp = D.x + 6 * f;
         for (int i = 0; i < 6; i++) { c0 -= Bi[i * 3] * xp[i]; c1 -= Bi[i * 3 + 1] * xp[i]; c2 -= Bi[i * 3 + 2] * xp[i]; }
     }
+    if (G > 1) { c0 = ba_group_sum<G>(c0); c1 = ba_group_sum<G>(c1); c2 = ba_group_sum<G>(c2); }
+    if (!live || g != 0) return;
     const double* Di = D.Dinv + 9 * (long long)l;
     double* xl = D.x + 6LL * D.nfree + 3 * (long long)l;
     xl[0] = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
@@ -277,15 +305,21 @@ void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial,
     if (nb > 0) hipLaunchKernelGGL(k_ba_errors, dim3(nb), dim3(256), 0, s, D, hd, partial);
     hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, partial, nb, out, 0);
 }
+#define BA_SMALL_MAP_LANDMARKS 32768      // up to here eight lanes share a landmark (see k_ba_lin_landmark)
 void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
 {
-    if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
+    if (D.L > 0 && D.L <= BA_SMALL_MAP_LANDMARKS) hipLaunchKernelGGL(k_ba_lin_landmark<8>, dim3(nblk(8LL * D.L, 256)), dim3(256), 0, s, D, hd);
+    else if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark<1>, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
     // few keyframes with long edge lists (local BA): a workgroup per keyframe; maps with thousands of keyframes: a wave each (measured:
     // the workgroup form costs config 5 another 60 us per linearisation, the wave form costs config 4 40 us)
     if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nfree), dim3(256), 0, s, D, hd);
     else if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
 }
-void ba_launch_backsub(hipStream_t s, const BaDev& D) { if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub, dim3(nblk(D.L, 256)), dim3(256), 0, s, D); }
+void ba_launch_backsub(hipStream_t s, const BaDev& D)
+{
+    if (D.L > 0 && D.L <= BA_SMALL_MAP_LANDMARKS) hipLaunchKernelGGL(k_ba_backsub<8>, dim3(nblk(8LL * D.L, 256)), dim3(256), 0, s, D);
+    else if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub<1>, dim3(nblk(D.L, 256)), dim3(256), 0, s, D);
+}
 void ba_launch_update(hipStream_t s, const BaDev& D)
 {
     const int n = D.L > D.nfree ? D.L : D.nfree;

@@ -125,9 +125,12 @@ __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_d
 // One workgroup (4 waves) per free pose: the waves take every fourth 64-edge run of the pose's list, reduce inside the wave by a fixed
 // butterfly and are added wave 0..3 by wave 0.  (One WAVE per pose, as in round 1, left a 20-keyframe local BA with 20 waves on a chip
 // with room for 8192, and config 5 with 2000: 56 us resp. 65 us per call.)
-__global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D, double huber_delta)
+// NW waves per keyframe: 4, or 16 when a map has few keyframes (a local BA's 20 workgroups leave the chip empty either way, and
+// with 1300 edges per keyframe a thread of 256 walked five of them one after the other)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_ba_lin_pose(BaDev D, double huber_delta)
 {
-    __shared__ double part[4][28];
+    __shared__ double part[NW][28];
     const int f = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (f >= D.nfree) return;
     const int pi = D.pose_of_free[f];
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D, double huber_delta
     double H[21], b[6];
     for (int i = 0; i < 21; i++) H[i] = 0;
     for (int i = 0; i < 6; i++) b[i] = 0;
-    for (int k = D.pose_first[f] + threadIdx.x; k < D.pose_first[f + 1]; k += 256) {
+    for (int k = D.pose_first[f] + threadIdx.x; k < D.pose_first[f + 1]; k += 64 * NW) {
         const int e = D.pose_edges[k];
         if (!D.active[e]) continue;
         double er[2], A[6], B[12];
@@ -161,7 +164,9 @@ __global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D, double huber_delta
     }
     __syncthreads();
     if (threadIdx.x < 27) {
-        const double v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        double v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+#pragma unroll
+        for (int w = 4; w < NW; w++) v += part[w][threadIdx.x];                                          // wave 0 .. NW-1: fixed order
         if (threadIdx.x >= 21) D.bp[6 * (long long)f + (threadIdx.x - 21)] = v;
         else {
             int i = 0, m = threadIdx.x;                       // packed upper-triangle index -> (i, j)
@@ -312,7 +317,9 @@ void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
     else if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark<1>, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
     // few keyframes with long edge lists (local BA): a workgroup per keyframe; maps with thousands of keyframes: a wave each (measured:
     // the workgroup form costs config 5 another 60 us per linearisation, the wave form costs config 4 40 us)
-    if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nfree), dim3(256), 0, s, D, hd);
+    // (16 waves per keyframe measured no faster than 4 at 20 keyframes x 1300 edges: 22.1 against 21.1 us -- the keyframe's edges are
+    //  a CU's worth of f64 work either way; more CUs per keyframe would need a second reduction stage)
+    if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_ba_lin_pose<4>, dim3(D.nfree), dim3(256), 0, s, D, hd);
     else if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
 }
 void ba_launch_backsub(hipStream_t s, const BaDev& D)

@@ -227,13 +227,14 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 
 // one workgroup (4 waves) per free pose: bs = bp - sum over its edges of Hpl_e db(l_e); wave partials added 0..3 (fixed order)
-__global__ __launch_bounds__(256) void k_sp_bschur(BaDev D, const double* __restrict__ db, double* __restrict__ bs)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_sp_bschur(BaDev D, const double* __restrict__ db, double* __restrict__ bs)
 {
-    __shared__ double part[4][6];
+    __shared__ double part[NW][6];
     const int f = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (f >= D.nfree) return;
     double c[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int k = D.pose_first[f] + threadIdx.x; k < D.pose_first[f + 1]; k += 256) {
+    for (int k = D.pose_first[f] + threadIdx.x; k < D.pose_first[f + 1]; k += 64 * NW) {
         const int e = D.pose_edges[k];
         if (!D.active[e]) continue;
         const double* B = D.Hpl + 18 * (long long)e;
@@ -244,7 +245,12 @@ __global__ __launch_bounds__(256) void k_sp_bschur(BaDev D, const double* __rest
         for (int s = 32; s >= 1; s >>= 1) c[i] += __shfl_xor(c[i], s, 64);
     if (lane == 0) for (int i = 0; i < 6; i++) part[wv][i] = c[i];
     __syncthreads();
-    if (threadIdx.x < 6) bs[6 * (long long)f + threadIdx.x] = D.bp[6 * (long long)f + threadIdx.x] - (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
+    if (threadIdx.x < 6) {
+        double v = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+#pragma unroll
+        for (int w = 4; w < NW; w++) v += part[w][threadIdx.x];                                          // wave 0 .. NW-1: fixed order
+        bs[6 * (long long)f + threadIdx.x] = D.bp[6 * (long long)f + threadIdx.x] - v;
+    }
 }
 
 // one wave per free pose: bs = bp - sum over its edges of Hpl_e db(l_e), fixed order
@@ -870,7 +876,8 @@ void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, cons
 }
 void sp_launch_bschur(hipStream_t s, const BaDev& D, const double* db, double* bs)
 {
-    if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_sp_bschur, dim3(D.nfree), dim3(256), 0, s, D, db, bs);
+    if (D.nfree > 0 && D.nfree < 64) hipLaunchKernelGGL(k_sp_bschur<16>, dim3(D.nfree), dim3(1024), 0, s, D, db, bs);
+    else if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_sp_bschur<4>, dim3(D.nfree), dim3(256), 0, s, D, db, bs);
     else if (D.nfree > 0) hipLaunchKernelGGL(k_sp_bschur_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, db, bs);
 }
 void sp_launch_add_lambda(hipStream_t s, const int* diag, int nfree, double lambda, double* Hb)

@@ -73,7 +73,7 @@ __device__ __forceinline__ bool chol6(const double* H, const double* b, double* 
 __global__ __launch_bounds__(PO_TPB) void k_pose_opt(PoseDev D)
 {
     __shared__ double red[5 * 28];
-    __shared__ double s_pose[7], s_Rt[12], s_x[6];
+    __shared__ double s_pose[7], s_x[6];
     __shared__ int s_ok;
     const int f = blockIdx.x, tid = threadIdx.x;
     const int e0 = D.first[f], e1 = D.first[f + 1], n = e1 - e0;

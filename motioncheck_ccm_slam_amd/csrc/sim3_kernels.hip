@@ -91,7 +91,7 @@ __device__ __forceinline__ void s3_xf(const double* S, S3Xf* f)
 __global__ __launch_bounds__(S3_TPB) void k_sim3_opt(Sim3Dev D)
 {
     __shared__ double red[4 * 36];
-    __shared__ double s_S[8], s_new[8], s_x[7];
+    __shared__ double s_S[8], s_x[7];
     __shared__ S3Xf s_f[15], s_i[15];            // [0] = current estimate, [1 + 2d], [2 + 2d] = +delta, -delta along d
     __shared__ int s_ok;
     const int pb = blockIdx.x, tid = threadIdx.x;

@@ -59,7 +59,9 @@ void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const un
 void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc, const PcgCoarse& C);
 int pcg_coarse_dim(int nfree);
 int pcg_coarse_parts(int nfree);
-void pcg_launch_coarse_build(hipStream_t, const double* Hb, const uint8_t* map, const int* id, int nfree, double* Ac);
+void pcg_launch_coarse_build(hipStream_t, const double* Hb, const uint8_t* map, const int* id, int nfree, const double* svec, const double* cen, double* Ac);
+int pcg_coarse_aggregates(int nfree);
+int pcg_coarse_agg_keyframes(int nfree);
 void pcg_launch_coarse_mirror(hipStream_t, double* A, int ncp);
 void pcg_launch_coarse_invert(hipStream_t, double* A, int ncp, double* D, int* bad);
 int pcg_coarse_pitch(int nfree);
@@ -81,7 +83,7 @@ struct BaState {
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
            partial, scal, flags, info_dev, tmp_ll, pp_diag, gather,
            sp_cnt, sp_off, sp_key, sp_val, sp_key2, sp_val2, sp_map, sp_id, sp_tmp, blk_row, blk_col, diag_id, seg_start, seg_end,
-           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw;
+           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw, pcg_svec;
 };
 void ba_state_free(BaState* s)
 {
@@ -96,7 +98,7 @@ void ba_state_free(BaState* s)
                       &s->partial, &s->scal, &s->flags, &s->info_dev, &s->tmp_ll, &s->pp_diag, &s->gather,
                       &s->sp_cnt, &s->sp_off, &s->sp_key, &s->sp_val, &s->sp_key2, &s->sp_val2, &s->sp_map, &s->sp_id, &s->sp_tmp, &s->blk_row,
                       &s->blk_col, &s->diag_id, &s->seg_start, &s->seg_end, &s->ent_key, &s->ent_val, &s->ent_key2, &s->ent_val2, &s->row_ptr,
-                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc, &s->pcg_aci, &s->pcg_coarse, &s->pcg_acw };
+                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc, &s->pcg_aci, &s->pcg_coarse, &s->pcg_acw, &s->pcg_svec };
     for (DevBuf* b : all) b->release();
     delete s;
 }
@@ -436,7 +438,22 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         {
             const size_t nc = (size_t)pcg_coarse_dim(nfree), ncp = (size_t)pcg_coarse_pitch(nfree);
             CCM_RESERVE(c, S.pcg_aci, ncp * ncp * 8 + 64); CCM_RESERVE(c, S.pcg_acw, (ncp * ncp + 48 * 48) * 8 + 64);   // + one block of scratch
-            CCM_RESERVE(c, S.pcg_coarse, ((size_t)n + nc + (size_t)pcg_coarse_parts(nfree) + 64) * 8);    // rcl (<= n), yc, cpart
+            CCM_RESERVE(c, S.pcg_coarse, (2 * nc + (size_t)pcg_coarse_parts(nfree) + 64) * 8);            // P^T r, yc, cpart
+            // the scale columns of the prolongation: keyframe translations as they are now, and each aggregate's mean
+            const int A = pcg_coarse_agg_keyframes(nfree), nagg = pcg_coarse_aggregates(nfree);
+            std::vector<double> sv(3 * (size_t)nfree + 3 * (size_t)nagg, 0.0);
+            for (int f = 0; f < nfree; f++) for (int q = 0; q < 3; q++) sv[3 * (size_t)f + q] = pb->poses[7 * (size_t)pose_of_free[f] + 4 + q];
+            for (int I = 0; I < nagg; I++) {
+                const int f0 = I * A, f1 = std::min(nfree, f0 + A);
+                for (int q = 0; q < 3; q++) {
+                    double m = 0;
+                    for (int f = f0; f < f1; f++) m += sv[3 * (size_t)f + q];
+                    sv[3 * (size_t)nfree + 3 * I + q] = m / std::max(1, f1 - f0);
+                }
+            }
+            CCM_RESERVE(c, S.pcg_svec, sv.size() * 8 + 64);
+            CCM_HIP(c, hipMemcpyAsync(S.pcg_svec.p, sv.data(), sv.size() * 8, hipMemcpyHostToDevice, st));
+            CCM_HIP(c, hipStreamSynchronize(st));                                                         // sv is a local
         }
         CCM_HIP(c, hipGetLastError());
     }
@@ -457,9 +474,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
             CCM_HIP(c, hipEventCreateWithFlags(&S.ev_hb, hipEventDisableTiming));
         }
         PC.Aci = S.pcg_aci.as<double>();
-        PC.rcl = S.pcg_coarse.as<double>();
-        PC.yc = PC.rcl + n;
+        PC.rc = S.pcg_coarse.as<double>();
+        PC.yc = PC.rc + nc;
         PC.cpart = PC.yc + nc;
+        PC.svec = S.pcg_svec.as<double>();
+        PC.cen = PC.svec + 3 * (size_t)nfree;
     }
     // The PCG inner loop is two small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
@@ -624,7 +643,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         auto start_inversion = [&]() -> int {
                             double* Aw = S.pcg_acw.as<double>();
                             CCM_HIP(c, hipMemsetAsync(info_dev + 4, 0, 4, S.side));
-                            pcg_launch_coarse_build(S.side, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, Aw);
+                            pcg_launch_coarse_build(S.side, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, PC.svec, PC.cen, Aw);
                             CCM_HIP(c, hipEventRecord(S.ev_hb, S.side));                 // awaited before the next trial overwrites Hb
                             hb_in_use = true;
                             pcg_launch_coarse_invert(S.side, Aw, ncp, Aw + (size_t)ncp * ncp, info_dev + 4);

@@ -352,69 +352,113 @@ __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, 
 
 // Second level of the preconditioner (additive two-level Schwarz): the cluster inverses above damp the error inside a
 // cluster, but the slowly varying error along the trajectory (many keyframes drifting together) converges only as fast as
-// information travels from cluster to cluster.  The coarse space has 6 unknowns per aggregate of pcg_agg_clusters() clusters
-// (one rigid increment shared by the aggregate's keyframes: R sums the 6-vectors of an aggregate), its matrix
-// Ac = R H R^T is dense and small (6 nagg squared), inverted once per LM trial (block Gauss-Jordan below), and
-//   z = Minv r + R^T Ac^-1 R r.
-// Measured on the 2000-keyframe graph (first LM trial, relative residual 1e-8): 345 PCG iterations with the cluster
-// level alone, 137 with 16-keyframe aggregates, 112 with 8-keyframe aggregates.
+// information travels from cluster to cluster.  Coarse space, 7 unknowns per aggregate of A = PCG_CL * pcg_agg_clusters()
+// keyframes: a rigid increment (6) and a scale change about the aggregate's centre (a monocular map with one fixed keyframe
+// has a free scale; its local version is the softest deformation of a trajectory piece), interpolated LINEARLY between the
+// aggregate centres (hat functions: keyframe f takes 1 - a of aggregate I and a of I + 1, x = (f + 1/2) / A - 1/2 = I + a;
+// the ends are clamped).  P = prolongation (n x 7 nagg), Ac = P^T H P dense and small, inverted once per LM trial (block
+// Gauss-Jordan below), and      z = Minv r + P Ac^-1 P^T r.
+// Iterations of a late LM trial of config 5 (lambda = 0.04, relative residual 1e-6; tools/gba_coarse_study.py reproduces the
+// counts on the CPU): cluster level alone 1165, piecewise-constant rigid aggregates (round 2 until here) 517, hat functions 148,
+// hat functions + scale 98.
 #ifndef PCG_AGG
 #define PCG_AGG 2                // clusters per aggregate up to PCG_COARSE_MAX coarse unknowns; doubled beyond (at most 8)
 #endif
-#define PCG_COARSE_MAX 1536
-// clusters per aggregate for a map of `nfree` free keyframes: the smallest of PCG_AGG, 2 PCG_AGG, ... (<= 8: a wave spreads a
-// coarse value over its aggregate's keyframes, one per lane) that keeps the coarse system within PCG_COARSE_MAX unknowns
-// (its inversion is cubic and has to fit inside one LM trial)
+#define PCG_CDOF 7               // coarse unknowns per aggregate
+#define PCG_COARSE_MAX 1792
+// clusters per aggregate for a map of `nfree` free keyframes: the smallest of PCG_AGG, 2 PCG_AGG, ... (<= 8) that keeps the coarse
+// system within PCG_COARSE_MAX unknowns (its inversion is cubic and has to fit inside one LM trial)
 __host__ __device__ inline int pcg_agg_clusters(int nfree)
 {
     int agg = PCG_AGG;
-    while (2 * agg * PCG_CL <= 64 && 6 * ((nfree + PCG_CL * agg - 1) / (PCG_CL * agg)) > PCG_COARSE_MAX) agg *= 2;
+    while (2 * agg * PCG_CL <= 64 && PCG_CDOF * ((nfree + PCG_CL * agg - 1) / (PCG_CL * agg)) > PCG_COARSE_MAX) agg *= 2;
     return agg;
 }
-// upper triangle of Ac, row-major with pitch ncp: one workgroup per aggregate pair I <= J, thread =
-// keyframe pair (i, j), the 36 sums reduced over the workgroup in a fixed order (the ranks of a sharded solve must get
-// the same bits)
-__global__ __launch_bounds__(256) void k_pcg_coarse_build(const double* __restrict__ Hb, const uint8_t* __restrict__ map, const int* __restrict__ id,
-                                                          int nfree, int nagg, int ncp, double* __restrict__ Ac)
+// the two aggregates keyframe f interpolates between, and its weights (w0 + w1 = 1)
+struct PcgHat { int i0, i1; double w0, w1; };
+__host__ __device__ inline PcgHat pcg_hat(int f, int A, int nagg)
 {
-    __shared__ double red[4][36];
+    const double x = ((double)f + 0.5) / (double)A - 0.5;          // multiples of 1 / (2A): exact
+    const int I = (int)floor(x);
+    const double al = x - (double)I;
+    PcgHat h;
+    h.i0 = min(max(I, 0), nagg - 1); h.i1 = min(I + 1, nagg - 1);
+    h.w0 = 1.0 - al; h.w1 = al;
+    if (h.i0 == h.i1) { h.w0 = 1.0; h.w1 = 0.0; }
+    return h;
+}
+// weight of keyframe f in aggregate I
+__host__ __device__ inline double pcg_hat_weight(int f, int I, int A, int nagg)
+{
+    const PcgHat h = pcg_hat(f, A, nagg);
+    return (h.i0 == I ? h.w0 : 0.0) + (h.i1 == I ? h.w1 : 0.0);
+}
+// keyframes with a non-zero weight in aggregate I: [first, last)
+__host__ __device__ inline void pcg_hat_support(int I, int A, int nfree, int& first, int& last)
+{
+    first = max(0, A * I - A / 2); last = min(nfree, A * I + A + A / 2);
+}
+// upper triangle of Ac = P^T H P, row-major with pitch ncp: one workgroup per aggregate pair I <= J, thread = keyframe pair
+// (i, j) of the two supports, the 49 sums reduced over the workgroup in a fixed order (the ranks of a sharded solve must get
+// the same bits).  Column 6 of keyframe i's 6 x 7 basis W_i is (0, 0, 0, t_i - c_I): svec holds t_i, cen the aggregate centres.
+__global__ __launch_bounds__(256) void k_pcg_coarse_build(const double* __restrict__ Hb, const uint8_t* __restrict__ map, const int* __restrict__ id,
+                                                          int nfree, int nagg, int ncp, const double* __restrict__ svec, const double* __restrict__ cen,
+                                                          double* __restrict__ Ac)
+{
+    __shared__ double red[4][PCG_CDOF * PCG_CDOF];
     const int I = blockIdx.y, J = blockIdx.x;
     if (J < I) return;
-    const int ag_kf = PCG_CL * pcg_agg_clusters(nfree);
-    const int i0 = I * ag_kf, j0 = J * ag_kf;
-    const int ni = min(ag_kf, nfree - i0), nj = min(ag_kf, nfree - j0);
-    double acc[36];
+    const int A = PCG_CL * pcg_agg_clusters(nfree);
+    int i0, i1, j0, j1;
+    pcg_hat_support(I, A, nfree, i0, i1); pcg_hat_support(J, A, nfree, j0, j1);
+    const int ni = i1 - i0, nj = j1 - j0;
+    double acc[PCG_CDOF * PCG_CDOF];
 #pragma unroll
-    for (int e = 0; e < 36; e++) acc[e] = 0.0;
+    for (int e = 0; e < PCG_CDOF * PCG_CDOF; e++) acc[e] = 0.0;
     for (int t = threadIdx.x; t < ni * nj; t += 256) {
         const int i = i0 + t / nj, j = j0 + t % nj;
         const int a = min(i, j), b = max(i, j);
         const long long idx = (long long)a * nfree + b;
         if (!map[idx]) continue;
+        const double wij = pcg_hat_weight(i, I, A, nagg) * pcg_hat_weight(j, J, A, nagg);
+        if (wij == 0.0) continue;
         const double* B = Hb + 36LL * id[idx];
+        double si[3], sj[3];
 #pragma unroll
-        for (int d = 0; d < 6; d++)
+        for (int q = 0; q < 3; q++) { si[q] = svec[3 * i + q] - cen[3 * I + q]; sj[q] = svec[3 * j + q] - cen[3 * J + q]; }
+        double col6[6], row6[6] = { 0, 0, 0, 0, 0, 0 }, corner = 0.0;
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            double c6 = 0.0;
 #pragma unroll
             for (int e = 0; e < 6; e++) {
                 // block (a, b) is stored for a <= b; (i, j) with i > j is its transpose; of a diagonal block the upper half counts
                 const double v = i < j ? B[6 * d + e] : (i > j ? B[6 * e + d] : (d <= e ? B[6 * d + e] : B[6 * e + d]));
-                acc[6 * d + e] += v;
+                acc[PCG_CDOF * d + e] += wij * v;
+                if (e >= 3) c6 += v * sj[e - 3];
+                if (d >= 3) row6[e] += si[d - 3] * v;
             }
+            col6[d] = c6;
+            if (d >= 3) corner += si[d - 3] * c6;
+        }
+#pragma unroll
+        for (int d = 0; d < 6; d++) { acc[PCG_CDOF * d + 6] += wij * col6[d]; acc[PCG_CDOF * 6 + d] += wij * row6[d]; }
+        acc[PCG_CDOF * 6 + 6] += wij * corner;
     }
 #pragma unroll
-    for (int e = 0; e < 36; e++) {
+    for (int e = 0; e < PCG_CDOF * PCG_CDOF; e++) {
         double v = acc[e];
         for (int st = 32; st >= 1; st >>= 1) v += __shfl_xor(v, st, 64);
         acc[e] = v;
     }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int e = 0; e < 36; e++) red[threadIdx.x >> 6][e] = acc[e];
+        for (int e = 0; e < PCG_CDOF * PCG_CDOF; e++) red[threadIdx.x >> 6][e] = acc[e];
     }
     __syncthreads();
-    if (threadIdx.x < 36) {
-        const int d = threadIdx.x / 6, e = threadIdx.x - 6 * d;
-        const int r = 6 * I + d, c = 6 * J + e;
+    if (threadIdx.x < PCG_CDOF * PCG_CDOF) {
+        const int d = threadIdx.x / PCG_CDOF, e = threadIdx.x - PCG_CDOF * d;
+        const int r = PCG_CDOF * I + d, c = PCG_CDOF * J + e;
         if (r <= c) Ac[(long long)r * ncp + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     }
 }
@@ -427,6 +471,7 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_complete(double* __restrict_
     const int r = (int)(i / ncp), c = (int)(i - (long long)r * ncp);
     if (r >= nc || c >= nc) A[i] = r == c ? 1.0 : 0.0;
     else if (r > c) A[i] = A[(long long)c * ncp + r];
+    else if (r == c && A[i] == 0.0) A[i] = 1.0;      // an aggregate whose keyframes all sit at one point has no scale column: the unknown stays inert
 }
 // after the inversion: the upper triangle is mirrored so that the preconditioner is exactly symmetric
 __global__ __launch_bounds__(256) void k_pcg_coarse_mirror(double* __restrict__ A, int ncp)
@@ -560,26 +605,41 @@ void pcg_launch_coarse_invert(hipStream_t s, double* A, int ncp, double* D, int*
 // yc = Ac^-1 (R r), z += R^T yc: rcl holds the per-cluster sums of the residual (written by k_pcg_init / k_pcg_update), a
 // wave per coarse row (aggregate I, component d) which then adds its value to component d of the aggregate's keyframes;
 // cpart[workgroup] = the workgroup's share of (R r) . yc, which is the coarse level's contribution to r.z
-__global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ Aci, int nc, int ncp, const double* __restrict__ rcl, int ncl,
-                                                    double* __restrict__ yc, double* __restrict__ cpart, double* __restrict__ z, int nfree)
+// P^T r: one thread per coarse unknown walks the keyframes of its aggregate's support in order (fixed summation order)
+__global__ __launch_bounds__(256) void k_pcg_restrict(const double* __restrict__ r, const double* __restrict__ svec, const double* __restrict__ cen,
+                                                      int nfree, int nagg, double* __restrict__ rc)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= PCG_CDOF * nagg) return;
+    const int I = q / PCG_CDOF, d = q - PCG_CDOF * I;
+    const int A = PCG_CL * pcg_agg_clusters(nfree);
+    int f0, f1;
+    pcg_hat_support(I, A, nfree, f0, f1);
+    double s = 0.0;
+    for (int f = f0; f < f1; f++) {
+        const double wt = pcg_hat_weight(f, I, A, nagg);
+        if (d < 6) s += wt * r[6LL * f + d];
+        else {
+            const double* rf = r + 6LL * f + 3; const double* t = svec + 3LL * f; const double* c = cen + 3 * I;
+            s += wt * (((t[0] - c[0]) * rf[0] + (t[1] - c[1]) * rf[1]) + (t[2] - c[2]) * rf[2]);
+        }
+    }
+    rc[q] = s;
+}
+// yc = Ac^-1 (P^T r), one wave per row; cpart = the workgroup's share of (P^T r) . yc  (= r . (P yc), the coarse part of r.z)
+__global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ Aci, int nc, int ncp, const double* __restrict__ rcg,
+                                                    double* __restrict__ yc, double* __restrict__ cpart)
 {
     extern __shared__ double rc[];
     __shared__ double dots[4];
-    const int agg = pcg_agg_clusters(nfree);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = blockIdx.x * 4 + wv;
-    // the row of the inverse is requested first: its latency passes under the assembly of R r
+    // the row of the inverse is requested first: its latency passes under the copy of P^T r
     constexpr int PRE = 24;                                   // 64 * 24 = 1536 columns in registers, the rest (larger maps) afterwards
     double av[PRE];
     const double* A = Aci + (long long)min(row, nc - 1) * ncp;
 #pragma unroll
     for (int q = 0; q < PRE; q++) { const int c = lane + 64 * q; av[q] = c < nc ? A[c] : 0.0; }
-    for (int i = threadIdx.x; i < nc; i += 256) {
-        const int I = i / 6, d = i - 6 * I;
-        double s = 0;
-#pragma unroll
-        for (int a = 0; a < agg; a++) { const int cl = I * agg + a; if (cl < ncl) s += rcl[6 * cl + d]; }
-        rc[i] = s;
-    }
+    for (int i = threadIdx.x; i < nc; i += 256) rc[i] = rcg[i];
     __syncthreads();
     double s = 0;
     if (row < nc) {
@@ -588,34 +648,33 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
         for (int c = lane + 64 * PRE; c < nc; c += 64) s += A[c] * rc[c];
     }
     for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
-    if (row < nc && lane < PCG_CL * agg) {
-        const int I = row / 6, kf = I * PCG_CL * agg + lane;
-        if (kf < nfree) z[6LL * kf + (row - 6 * I)] += s;
-    }
     if (lane == 0) { if (row < nc) yc[row] = s; dots[wv] = row < nc ? s * rc[row] : 0.0; }
     __syncthreads();
     if (threadIdx.x == 0) cpart[blockIdx.x] = ((dots[0] + dots[1]) + dots[2]) + dots[3];
+}
+// z += P yc: one thread per scalar unknown
+__global__ __launch_bounds__(256) void k_pcg_prolong(const double* __restrict__ yc, const double* __restrict__ svec, const double* __restrict__ cen,
+                                                     int nfree, int nagg, double* __restrict__ z)
+{
+    const long long o = blockIdx.x * 256LL + threadIdx.x;
+    if (o >= 6LL * nfree) return;
+    const int f = (int)(o / 6), d = (int)(o - 6LL * f);
+    const PcgHat h = pcg_hat(f, PCG_CL * pcg_agg_clusters(nfree), nagg);
+    const double* y0 = yc + PCG_CDOF * h.i0; const double* y1 = yc + PCG_CDOF * h.i1;
+    double v = h.w0 * y0[d] + h.w1 * y1[d];
+    if (d >= 3) {
+        const double t = svec[3LL * f + (d - 3)];
+        v += h.w0 * ((t - cen[3 * h.i0 + (d - 3)]) * y0[6]) + h.w1 * ((t - cen[3 * h.i1 + (d - 3)]) * y1[6]);
+    }
+    z[o] += v;
 }
 
 // state vector layout in `w`: x | r | z | p (even iterations) | Ap | p (odd iterations)  (each n doubles); scalars in sc[]:
 //   sc[0] rz, sc[1] |b|^2, sc[2] |r|^2, sc[3] min p.Ap seen, sc[4] iterations
 #define PCG_UPD_TPB 192       // 4 clusters of PCG_CN scalars: a cluster never straddles two blocks
 static_assert(PCG_UPD_TPB % PCG_CN == 0, "a block must hold whole clusters");
-// R r, first half: the 6 component sums of every cluster of the block (threads 0..5 of a cluster, keyframes in order)
-__device__ __forceinline__ void pcg_cluster_sums(const double* rs, double* __restrict__ rcl, int nfree)
-{
-    if (!rcl) return;
-    const int li = threadIdx.x % PCG_CN, cl = (int)(((long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x) / PCG_CN);
-    if (li < 6 && cl < (nfree + PCG_CL - 1) / PCG_CL) {
-        const double* q = rs + (threadIdx.x - li) + li;
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < PCG_CL; k++) s += q[6 * k];
-        rcl[6 * cl + li] = s;
-    }
-}
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restrict__ b, const double* __restrict__ Minv, int nfree,
-                                                          double* __restrict__ w, double* __restrict__ part, double* __restrict__ rcl)
+                                                          double* __restrict__ w, double* __restrict__ part)
 {
     __shared__ double rs[PCG_UPD_TPB];
     __shared__ double red[2][3];
@@ -624,7 +683,6 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restri
     const double ri = o < n ? b[o] : 0.0;
     rs[threadIdx.x] = ri;
     __syncthreads();
-    pcg_cluster_sums(rs, rcl, nfree);
     double rz = 0, bb = 0;
     if (o < n) {
         const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
@@ -753,7 +811,7 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
 // block holds 4 whole clusters whose new residuals are shared through LDS.  Every block re-reduces p.Ap itself.
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __restrict__ Minv, int nfree, double* __restrict__ w,
                                                             const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part,
-                                                            int parity, double* __restrict__ rcl)
+                                                            int parity)
 {
     __shared__ double red[4];
     __shared__ double red2[2][3];
@@ -775,7 +833,6 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     const double ri = r_old - alpha * ap;
     rs[threadIdx.x] = ri;
     __syncthreads();
-    pcg_cluster_sums(rs, rcl, nfree);
     double rz = 0, rr = 0;
     if (o < n) {
         const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
@@ -895,30 +952,35 @@ hipError_t pcg_launch_minv(hipStream_t s, const double* Hb, const int* blk_row, 
     return hipSuccess;
 }
 // coarse level: sizes, set-up (Ac into `Ac`, upper triangle row-major; the caller factors and inverts it, then mirrors)
-int pcg_coarse_dim(int nfree) { return 6 * nblk(nfree, PCG_CL * pcg_agg_clusters(nfree)); }
+int pcg_coarse_aggregates(int nfree) { return nblk(nfree, PCG_CL * pcg_agg_clusters(nfree)); }
+int pcg_coarse_agg_keyframes(int nfree) { return PCG_CL * pcg_agg_clusters(nfree); }
+int pcg_coarse_dim(int nfree) { return PCG_CDOF * pcg_coarse_aggregates(nfree); }
 int pcg_coarse_pitch(int nfree) { return nblk(pcg_coarse_dim(nfree), INV_B) * INV_B; }
 int pcg_coarse_parts(int nfree) { return nblk(pcg_coarse_dim(nfree), 4); }
 // Ac = R H R^T as a full (padded) matrix in `Ac`
-void pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, double* Ac)
+void pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, const double* svec, const double* cen, double* Ac)
 {
-    const int nagg = nblk(nfree, PCG_CL * pcg_agg_clusters(nfree)), nc = 6 * nagg, ncp = pcg_coarse_pitch(nfree);
-    hipLaunchKernelGGL(k_pcg_coarse_build, dim3(nagg, nagg), dim3(256), 0, s, Hb, map, id, nfree, nagg, ncp, Ac);
+    const int nagg = pcg_coarse_aggregates(nfree), nc = PCG_CDOF * nagg, ncp = pcg_coarse_pitch(nfree);
+    hipLaunchKernelGGL(k_pcg_coarse_build, dim3(nagg, nagg), dim3(256), 0, s, Hb, map, id, nfree, nagg, ncp, svec, cen, Ac);
     hipLaunchKernelGGL(k_pcg_coarse_complete, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, Ac, nc, ncp);
 }
 void pcg_launch_coarse_mirror(hipStream_t s, double* A, int ncp)
 {
     hipLaunchKernelGGL(k_pcg_coarse_mirror, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, A, ncp);
 }
+// z += P Ac^-1 P^T r  (r and z inside the PCG state vector w), and the coarse share of r.z into C.cpart
 static void pcg_launch_coarse(hipStream_t s, const PcgCoarse& C, int nfree, double* w)
 {
-    const int nc = pcg_coarse_dim(nfree);
-    hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, pcg_coarse_pitch(nfree), C.rcl, nblk(nfree, PCG_CL), C.yc, C.cpart,
-                       w + 2 * 6LL * nfree, nfree);
+    const int nagg = pcg_coarse_aggregates(nfree), nc = PCG_CDOF * nagg;
+    const long long n = 6LL * nfree;
+    hipLaunchKernelGGL(k_pcg_restrict, dim3(nblk(nc, 256)), dim3(256), 0, s, w + n, C.svec, C.cen, nfree, nagg, C.rc);
+    hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, pcg_coarse_pitch(nfree), C.rc, C.yc, C.cpart);
+    hipLaunchKernelGGL(k_pcg_prolong, dim3(nblk(n, 256)), dim3(256), 0, s, C.yc, C.svec, C.cen, nfree, nagg, w + 2 * n);
 }
 void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C)
 {
     const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
-    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part, C.Aci ? C.rcl : nullptr);
+    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part);
     if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
     hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
 }
@@ -930,7 +992,7 @@ void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const 
     const int ncp = C.Aci ? pcg_coarse_parts(nfree) : 0;
     hipLaunchKernelGGL(k_pcg_spmv, dim3(PCG_XCDS * nblk(nfree, PCG_XCDS)), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity,
                        C.cpart, ncp);
-    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity, C.Aci ? C.rcl : nullptr);
+    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity);
     if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
 }
 // publish the scalars of the last iteration (before the host reads them)

@@ -438,7 +438,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         {
             const size_t nc = (size_t)pcg_coarse_dim(nfree), ncp = (size_t)pcg_coarse_pitch(nfree);
             CCM_RESERVE(c, S.pcg_aci, ncp * ncp * 8 + 64); CCM_RESERVE(c, S.pcg_acw, (ncp * ncp + 48 * 48) * 8 + 64);   // + one block of scratch
-            CCM_RESERVE(c, S.pcg_coarse, (2 * nc + (size_t)pcg_coarse_parts(nfree) + 64) * 8);            // P^T r, yc, cpart
+            const size_t nrp = ((size_t)n / 192 + 2) * 4 * 7;                                                     // block partials of P^T r (ba_sparse.hip: PCG_UPD_TPB, PCG_RSLOTS, PCG_CDOF)
+            CCM_RESERVE(c, S.pcg_coarse, (nrp + nc + (size_t)pcg_coarse_parts(nfree) + 64) * 8);                // P^T r, yc, cpart
             // the scale columns of the prolongation: keyframe translations as they are now, and each aggregate's mean
             const int A = pcg_coarse_agg_keyframes(nfree), nagg = pcg_coarse_aggregates(nfree);
             std::vector<double> sv(3 * (size_t)nfree + 3 * (size_t)nagg, 0.0);
@@ -475,7 +476,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         }
         PC.Aci = S.pcg_aci.as<double>();
         PC.rc = S.pcg_coarse.as<double>();
-        PC.yc = PC.rc + nc;
+        PC.yc = PC.rc + ((size_t)n / 192 + 2) * 4 * 7;
         PC.cpart = PC.yc + nc;
         PC.svec = S.pcg_svec.as<double>();
         PC.cen = PC.svec + 3 * (size_t)nfree;

@@ -605,29 +605,52 @@ void pcg_launch_coarse_invert(hipStream_t s, double* A, int ncp, double* D, int*
 // yc = Ac^-1 (R r), z += R^T yc: rcl holds the per-cluster sums of the residual (written by k_pcg_init / k_pcg_update), a
 // wave per coarse row (aggregate I, component d) which then adds its value to component d of the aggregate's keyframes;
 // cpart[workgroup] = the workgroup's share of (R r) . yc, which is the coarse level's contribution to r.z
-// P^T r: one thread per coarse unknown walks the keyframes of its aggregate's support in order (fixed summation order)
-__global__ __launch_bounds__(256) void k_pcg_restrict(const double* __restrict__ r, const double* __restrict__ svec, const double* __restrict__ cen,
-                                                      int nfree, int nagg, double* __restrict__ rc)
+// P^T r comes from the kernels that make r (k_pcg_init, k_pcg_update): a block of PCG_UPD_TPB scalars is PCG_UPD_KF consecutive
+// keyframes, which touch at most PCG_RSLOTS consecutive aggregates (the first is pcg_hat(first keyframe).i0); thread (slot, d) walks
+// the block's keyframes in order and leaves its partial sum in rpart[block][slot][d].  k_pcg_coarse adds the two or three blocks
+// of an aggregate in block order: fixed summation order, no extra launch (a kernel of its own took 15 us per PCG iteration).
+#define PCG_UPD_TPB 192       // 4 clusters of PCG_CN scalars: a cluster never straddles two blocks
+#define PCG_UPD_KF (PCG_UPD_TPB / 6)
+#define PCG_RSLOTS 4          // PCG_UPD_KF / (aggregate >= 16 keyframes) + 2
+__device__ __forceinline__ void pcg_block_restrict(const double* rs, int nfree, int nagg, const double* __restrict__ svec, const double* __restrict__ cen,
+                                                   double* __restrict__ rpart)
 {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= PCG_CDOF * nagg) return;
-    const int I = q / PCG_CDOF, d = q - PCG_CDOF * I;
+    if (!rpart) return;                                            // (uniform: no coarse level in this solve)
+    // every thread (keyframe k of the block, component d) weights its residual for the keyframe's two aggregates; the thread of
+    // component 3 also forms the scale products; then thread (slot, d) adds the block's keyframes in order
+    __shared__ double cw[2][PCG_UPD_KF][PCG_CDOF];
+    __shared__ int ci0[PCG_UPD_KF], ci1[PCG_UPD_KF];
     const int A = PCG_CL * pcg_agg_clusters(nfree);
-    int f0, f1;
-    pcg_hat_support(I, A, nfree, f0, f1);
-    double s = 0.0;
-    for (int f = f0; f < f1; f++) {
-        const double wt = pcg_hat_weight(f, I, A, nagg);
-        if (d < 6) s += wt * r[6LL * f + d];
-        else {
-            const double* rf = r + 6LL * f + 3; const double* t = svec + 3LL * f; const double* c = cen + 3 * I;
-            s += wt * (((t[0] - c[0]) * rf[0] + (t[1] - c[1]) * rf[1]) + (t[2] - c[2]) * rf[2]);
-        }
+    const int f0 = blockIdx.x * PCG_UPD_KF;
+    {
+        const int k = threadIdx.x / 6, d = threadIdx.x - 6 * k, f = f0 + k;
+        if (f < nfree) {
+            const PcgHat h = pcg_hat(f, A, nagg);
+            const double r = rs[threadIdx.x];
+            cw[0][k][d] = h.w0 * r; cw[1][k][d] = h.w1 * r;
+            if (d == 3) {
+                const double* t = svec + 3LL * f; const double* c0 = cen + 3 * h.i0; const double* c1 = cen + 3 * h.i1;
+                const double* rf = rs + 6 * k + 3;
+                cw[0][k][6] = h.w0 * (((t[0] - c0[0]) * rf[0] + (t[1] - c0[1]) * rf[1]) + (t[2] - c0[2]) * rf[2]);
+                cw[1][k][6] = h.w1 * (((t[0] - c1[0]) * rf[0] + (t[1] - c1[1]) * rf[1]) + (t[2] - c1[2]) * rf[2]);
+                ci0[k] = h.i0; ci1[k] = h.i1;
+            }
+        } else if (d == 3) { ci0[k] = -1; ci1[k] = -1; }
     }
-    rc[q] = s;
+    __syncthreads();
+    if (threadIdx.x < PCG_RSLOTS * PCG_CDOF) {
+        const int slot = threadIdx.x / PCG_CDOF, d = threadIdx.x - PCG_CDOF * slot;
+        const int I = pcg_hat(f0, A, nagg).i0 + slot;
+        double s = 0.0;
+        for (int k = 0; k < PCG_UPD_KF; k++) {
+            if (ci0[k] == I) s += cw[0][k][d];
+            if (ci1[k] == I && ci1[k] != ci0[k]) s += cw[1][k][d];
+        }
+        rpart[((long long)blockIdx.x * PCG_RSLOTS + slot) * PCG_CDOF + d] = s;
+    }
 }
 // yc = Ac^-1 (P^T r), one wave per row; cpart = the workgroup's share of (P^T r) . yc  (= r . (P yc), the coarse part of r.z)
-__global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ Aci, int nc, int ncp, const double* __restrict__ rcg,
+__global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ Aci, int nc, int ncp, const double* __restrict__ rpart, int nfree,
                                                     double* __restrict__ yc, double* __restrict__ cpart)
 {
     extern __shared__ double rc[];
@@ -639,7 +662,20 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
     const double* A = Aci + (long long)min(row, nc - 1) * ncp;
 #pragma unroll
     for (int q = 0; q < PRE; q++) { const int c = lane + 64 * q; av[q] = c < nc ? A[c] : 0.0; }
-    for (int i = threadIdx.x; i < nc; i += 256) rc[i] = rcg[i];
+    {
+        const int A = PCG_CL * pcg_agg_clusters(nfree), nagg = nc / PCG_CDOF;
+        for (int i = threadIdx.x; i < nc; i += 256) {
+            const int I = i / PCG_CDOF, d = i - PCG_CDOF * I;
+            int f0, f1;
+            pcg_hat_support(I, A, nfree, f0, f1);
+            double sum = 0.0;
+            for (int b = f0 / PCG_UPD_KF; b <= (f1 - 1) / PCG_UPD_KF; b++) {            // the blocks of k_pcg_update that hold keyframes of I
+                const int slot = I - pcg_hat(b * PCG_UPD_KF, A, nagg).i0;
+                if (slot >= 0 && slot < PCG_RSLOTS) sum += rpart[((long long)b * PCG_RSLOTS + slot) * PCG_CDOF + d];
+            }
+            rc[i] = sum;
+        }
+    }
     __syncthreads();
     double s = 0;
     if (row < nc) {
@@ -671,10 +707,10 @@ __global__ __launch_bounds__(256) void k_pcg_prolong(const double* __restrict__ 
 
 // state vector layout in `w`: x | r | z | p (even iterations) | Ap | p (odd iterations)  (each n doubles); scalars in sc[]:
 //   sc[0] rz, sc[1] |b|^2, sc[2] |r|^2, sc[3] min p.Ap seen, sc[4] iterations
-#define PCG_UPD_TPB 192       // 4 clusters of PCG_CN scalars: a cluster never straddles two blocks
 static_assert(PCG_UPD_TPB % PCG_CN == 0, "a block must hold whole clusters");
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restrict__ b, const double* __restrict__ Minv, int nfree,
-                                                          double* __restrict__ w, double* __restrict__ part)
+                                                          double* __restrict__ w, double* __restrict__ part, int nagg, const double* __restrict__ svec,
+                                                          const double* __restrict__ cen, double* __restrict__ rpart)
 {
     __shared__ double rs[PCG_UPD_TPB];
     __shared__ double red[2][3];
@@ -683,6 +719,7 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restri
     const double ri = o < n ? b[o] : 0.0;
     rs[threadIdx.x] = ri;
     __syncthreads();
+    pcg_block_restrict(rs, nfree, nagg, svec, cen, rpart);
     double rz = 0, bb = 0;
     if (o < n) {
         const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
@@ -811,7 +848,8 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
 // block holds 4 whole clusters whose new residuals are shared through LDS.  Every block re-reduces p.Ap itself.
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __restrict__ Minv, int nfree, double* __restrict__ w,
                                                             const double* __restrict__ pap_part, const double* __restrict__ sc, double* __restrict__ part,
-                                                            int parity)
+                                                            int parity, int nagg, const double* __restrict__ svec, const double* __restrict__ cen,
+                                                            double* __restrict__ rpart)
 {
     __shared__ double red[4];
     __shared__ double red2[2][3];
@@ -833,6 +871,7 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     const double ri = r_old - alpha * ap;
     rs[threadIdx.x] = ri;
     __syncthreads();
+    pcg_block_restrict(rs, nfree, nagg, svec, cen, rpart);
     double rz = 0, rr = 0;
     if (o < n) {
         const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
@@ -968,19 +1007,20 @@ void pcg_launch_coarse_mirror(hipStream_t s, double* A, int ncp)
 {
     hipLaunchKernelGGL(k_pcg_coarse_mirror, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, A, ncp);
 }
-// z += P Ac^-1 P^T r  (r and z inside the PCG state vector w), and the coarse share of r.z into C.cpart
+// z += P Ac^-1 P^T r  (z inside the PCG state vector w; P^T r as block partials in C.rc, left there by k_pcg_init / k_pcg_update),
+// and the coarse share of r.z into C.cpart
 static void pcg_launch_coarse(hipStream_t s, const PcgCoarse& C, int nfree, double* w)
 {
     const int nagg = pcg_coarse_aggregates(nfree), nc = PCG_CDOF * nagg;
     const long long n = 6LL * nfree;
-    hipLaunchKernelGGL(k_pcg_restrict, dim3(nblk(nc, 256)), dim3(256), 0, s, w + n, C.svec, C.cen, nfree, nagg, C.rc);
-    hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, pcg_coarse_pitch(nfree), C.rc, C.yc, C.cpart);
+    hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, pcg_coarse_pitch(nfree), C.rc, nfree, C.yc, C.cpart);
     hipLaunchKernelGGL(k_pcg_prolong, dim3(nblk(n, 256)), dim3(256), 0, s, C.yc, C.svec, C.cen, nfree, nagg, w + 2 * n);
 }
 void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C)
 {
     const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
-    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part);
+    hipLaunchKernelGGL(k_pcg_init, dim3(nb), dim3(PCG_UPD_TPB), 0, s, b, Minv, nfree, w, part, C.Aci ? pcg_coarse_aggregates(nfree) : 0, C.svec, C.cen,
+                       C.Aci ? C.rc : nullptr);
     if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
     hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
 }
@@ -992,7 +1032,8 @@ void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const 
     const int ncp = C.Aci ? pcg_coarse_parts(nfree) : 0;
     hipLaunchKernelGGL(k_pcg_spmv, dim3(PCG_XCDS * nblk(nfree, PCG_XCDS)), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity,
                        C.cpart, ncp);
-    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity);
+    hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity, C.Aci ? pcg_coarse_aggregates(nfree) : 0,
+                       C.svec, C.cen, C.Aci ? C.rc : nullptr);
     if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
 }
 // publish the scalars of the last iteration (before the host reads them)

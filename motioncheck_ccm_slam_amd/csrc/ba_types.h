@@ -31,7 +31,7 @@ struct BaDev {
 // coarse level of the PCG preconditioner (ba_sparse.hip); Aci == nullptr switches it off
 struct PcgCoarse {
     double* Aci;                   // [nc][nc] inverse of the coarse matrix, nc = 7 per aggregate
-    double* rc;                    // [nc] restricted residual P^T r
+    double* rc;                    // [blocks of k_pcg_update][4][7] block partials of the restricted residual P^T r
     double* yc;                    // [nc] coarse correction
     double* cpart;                 // per workgroup of k_pcg_coarse: share of (P^T r) . yc
     const double* svec;            // [nfree][3] keyframe translations at the start of the call (the scale columns of P)

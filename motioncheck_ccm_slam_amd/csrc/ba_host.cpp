@@ -483,9 +483,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     }
     // The PCG inner loop is two small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
-    // Chunk lengths (even: the r.z slot parity is the same at the start of every chunk): 16 iterations per host round trip
-    // while far from the tolerance, 4 near the end, chosen from the contraction observed so far.
-    const int pcg_len[2] = {16, 4};
+    // Chunk lengths (even: the r.z slot parity is the same at the start of every chunk): graphs of 8 and of 2 iterations; a host
+    // round trip launches as many of them as the contraction observed so far says are still needed (rounded up to 2), then one
+    // publication kernel, and looks again -- with the hat-function coarse level a trial takes 20-100 iterations of 45 us, so
+    // iterations past convergence cost more than round trips.
+    const int pcg_len[2] = {8, 2};
     // Graphs: [level][length]; level 0 = the cluster level alone (first trial of a call: no coarse inverse exists yet), 1 = both levels.
     PcgCoarse PC0{};
     hipGraph_t pcg_graph[4] = {nullptr, nullptr, nullptr, nullptr}; hipGraphExec_t pcg_exec[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -499,7 +501,6 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 for (int k = 0; k < pcg_len[gi & 1]; k++)
                     pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
                                     nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pc);
-                pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pc);
                 hipError_t e1 = hipStreamEndCapture(st, &pcg_graph[gi]);
                 hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec[gi], pcg_graph[gi], nullptr, nullptr, 0) : e1;
                 if (e2 != hipSuccess) {
@@ -671,24 +672,26 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                             if (sc[2] <= tol2 * sc[1]) { solved = true; break; }
                             if (itc >= max_it) break;
                             // iterations still needed if |r|^2 keeps contracting as over the last round trip; without an estimate
-                            // (first round trip, stagnation) or far from the tolerance: full chunks
+                            // (first round trip, stagnation): 16, or 32 while there is no coarse level
                             const double rr = sc[2], target = tol2 * sc[1];
-                            int launches = (itc < 64 && !coarse_ready) ? 2 : 1, which = 0;
+                            int need = coarse_ready ? 16 : 32;
                             if (last_len > 0 && rr_prev > 0 && rr < rr_prev) {
-                                const double need = std::log(rr / target) / (std::log(rr_prev / rr) / last_len);
-                                if (need <= 12.0) { which = 1; launches = std::max(1, (int)std::ceil(need / pcg_len[1])); }
+                                const double est = std::log(rr / target) / (std::log(rr_prev / rr) / last_len);
+                                need = (int)std::min(16.0, std::max(2.0, std::ceil(est)));       // (CG speeds up as it goes: a longer forecast overshoots)
                             }
-                            rr_prev = rr; last_len = launches * pcg_len[which];
-                            hipGraphExec_t gexec = pcg_exec[glv + which];
-                            for (int rpt = 0; rpt < launches; rpt++) {
-                                if (gexec) CCM_HIP(c, hipGraphLaunch(gexec, st));
-                                else {
-                                    for (int k = 0; k < pcg_len[which]; k++)
-                                        pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                                        nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pcu);
-                                    pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
+                            const int n8 = need / pcg_len[0], n2 = (need - n8 * pcg_len[0] + pcg_len[1] - 1) / pcg_len[1];
+                            rr_prev = rr; last_len = n8 * pcg_len[0] + n2 * pcg_len[1];
+                            for (int which = 0; which < 2; which++) {
+                                hipGraphExec_t gexec = pcg_exec[glv + which];
+                                for (int rpt = 0; rpt < (which ? n2 : n8); rpt++) {
+                                    if (gexec) CCM_HIP(c, hipGraphLaunch(gexec, st));
+                                    else
+                                        for (int k = 0; k < pcg_len[which]; k++)
+                                            pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                                                            nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pcu);
                                 }
                             }
+                            pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                             itc += last_len;
                             if (side_todo && (rc = start_inversion())) return rc;
                         }

@@ -378,8 +378,8 @@ __host__ __device__ inline int pcg_agg_clusters(int nfree)
 struct PcgHat { int i0, i1; double w0, w1; };
 __host__ __device__ inline PcgHat pcg_hat(int f, int A, int nagg)
 {
-    const double x = ((double)f + 0.5) / (double)A - 0.5;          // multiples of 1 / (2A): exact
-    const int I = (int)floor(x);
+    const double x = ((double)f + 0.5) * (1.0 / (double)A) - 0.5;  // A is a power of two: multiples of 1 / (2A), exact
+    const int I = (int)(x + 1.0) - 1;                              // floor(x) for x >= -1
     const double al = x - (double)I;
     PcgHat h;
     h.i0 = min(max(I, 0), nagg - 1); h.i1 = min(I + 1, nagg - 1);
@@ -895,10 +895,12 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
 __global__ __launch_bounds__(64) void k_pcg_scalars(int nblk, const double* __restrict__ part, const double* __restrict__ cpart, int ncpart,
                                                     double* __restrict__ sc)
 {
-    if (threadIdx.x != 0) return;
+    // the same sums in the same order as a workgroup of k_pcg_spmv forms them (one thread walking the ~300 partials took 20 us)
     double rz = 0, rr = 0, rzc = 0;
-    for (int i = 0; i < nblk; i++) { rz += part[3 * i]; rr += part[3 * i + 1]; }
-    for (int i = 0; i < ncpart; i++) rzc += cpart[i];
+    for (int i = threadIdx.x; i < nblk; i += 64) { rz += part[3 * i]; rr += part[3 * i + 1]; }
+    for (int i = threadIdx.x; i < ncpart; i += 64) rzc += cpart[i];
+    for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); rzc += __shfl_xor(rzc, st, 64); }
+    if (threadIdx.x != 0) return;
     rz += rzc;
     const double pap = part[2];
     sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;

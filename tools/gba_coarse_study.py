@@ -116,7 +116,8 @@ def hat_cols_centred(per):
             for d in range(6): rows.append(6 * f + d); cols.append(7 * ag + d); vals.append(wt)
             for d in range(3): rows.append(6 * f + 3 + d); cols.append(7 * ag + 6); vals.append(wt * (tt[f, d] - cen[ag, d]))
     return sp.csr_matrix((vals, (rows, cols)), shape=(n, 7 * na))
-extra = [("hat functions over 16 keyframes", hat_cols(16, False)), ("  + scale", hat_cols(16, True)), ("  + scale, centred per aggregate", hat_cols_centred(16)),
+extra = [("hat functions over 32 keyframes + scale, centred", hat_cols_centred(32)), ("hat functions over 64 keyframes + scale, centred", hat_cols_centred(64)),
+         ("hat functions over 16 keyframes", hat_cols(16, False)), ("  + scale", hat_cols(16, True)), ("  + scale, centred per aggregate", hat_cols_centred(16)),
          ("hat functions over 8 keyframes", hat_cols(8, False)), ("  + scale", hat_cols(8, True))]
 for per in (8, 4, 2):
     extra.append(("rigid aggregates of %d keyframes (%d coarse unknowns)" % (per, 6 * ((nf + per - 1) // per)), agg_cols(per, False)))

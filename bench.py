@@ -357,11 +357,11 @@ def main():
             if rp["pcg_iterations"]:
                 per_it = rp["t_solve"] / rp["pcg_iterations"]
                 spmv_bytes = (2 * r["schur_blocks"] - 1999) * 288.0
-                roof["solve"] = {"kernels": "k_pcg_spmv + k_pcg_update + k_pcg_coarse (HIP graph)", "bound": "hbm",
+                roof["solve"] = {"kernels": "k_pcg_spmv + k_pcg_update + k_pcg_coarse + k_pcg_prolong (HIP graphs)", "bound": "hbm",
                                  "us_per_pcg_iteration_host_timed": round(per_it * 1e6, 2),
                                  "spmv_algorithmic_bytes": int(spmv_bytes), "achieved": round(spmv_bytes / per_it / 1e9, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(spmv_bytes / per_it / 1e9 / HBM_PEAK_GBS, 5),
-                                 "note": "whole PCG iteration (three kernels + host round trips) charged to the mat-vec's bytes"}
+                                 "note": "whole PCG iteration (four kernels + host round trips) charged to the mat-vec's bytes"}
             gba["roofline"] = roof
             if solo:
                 # BASELINE config 4 beside it: the local BA Mapping runs per keyframe (20 free + 10 fixed keyframes, 5000 points, 5 robust + 10

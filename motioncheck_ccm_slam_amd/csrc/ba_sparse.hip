@@ -492,26 +492,55 @@ static_assert(INV_B == 16 * INV_T, "256 threads tile a block");
 // D = A_kk^-1 by in-place Gauss-Jordan in LDS
 __global__ __launch_bounds__(256) void k_inv_diag(const double* __restrict__ A, int lda, int k, double* __restrict__ D, int* __restrict__ bad)
 {
-    __shared__ double a[INV_B][INV_B];
-    __shared__ double fcol[INV_B], prow[INV_B];
+    // Gauss-Jordan with the block in REGISTERS: thread (ty, tx) of the 16 x 16 workgroup owns the 3 x 3 elements (ty + 16 a, tx + 16 b);
+    // per pivot p the owners of column p and of row p publish them in LDS (two alternating buffers: one barrier per pivot), every
+    // thread reads the three column and three row values its elements need.  (With the block in LDS and two barriers per pivot the
+    // 19 diagonal blocks of config 5's coarse matrix took 73 us each -- 60 % of the inversion, which shares the GPU with the PCG.)
+    __shared__ double fcol[2][INV_B], prow[2][INV_B];
+    __shared__ int s_bad;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const double* Akk = A + ((long long)k * INV_B) * lda + (long long)k * INV_B;
-    for (int i = threadIdx.x; i < INV_B * INV_B; i += 256) a[i / INV_B][i % INV_B] = Akk[(long long)(i / INV_B) * lda + i % INV_B];
-    __syncthreads();
-    bool ok = true;
-    for (int p = 0; p < INV_B; p++) {
-        const double piv = a[p][p];
-        if (!(piv > 0.0)) ok = false;
-        const double ip = 1.0 / piv;
-        if (threadIdx.x < INV_B) { fcol[threadIdx.x] = a[threadIdx.x][p]; prow[threadIdx.x] = ((int)threadIdx.x == p ? 1.0 : a[p][threadIdx.x]) * ip; }
-        __syncthreads();
-        for (int e = threadIdx.x; e < INV_B * INV_B; e += 256) {
-            const int i = e / INV_B, j = e - i * INV_B;
-            a[i][j] = i == p ? prow[j] : ((j == p ? 0.0 : a[i][j]) - fcol[i] * prow[j]);
+    double a[INV_T][INV_T];
+#pragma unroll
+    for (int i = 0; i < INV_T; i++)
+#pragma unroll
+        for (int j = 0; j < INV_T; j++) a[i][j] = Akk[(long long)(ty + 16 * i) * lda + tx + 16 * j];
+    if (threadIdx.x == 0) s_bad = 0;
+    // publish column 0 and row 0
+#pragma unroll
+    for (int i = 0; i < INV_T; i++)
+#pragma unroll
+        for (int j = 0; j < INV_T; j++) {
+            if (tx + 16 * j == 0) fcol[0][ty + 16 * i] = a[i][j];
+            if (ty + 16 * i == 0) prow[0][tx + 16 * j] = a[i][j];
         }
+    __syncthreads();
+    for (int p = 0; p < INV_B; p++) {
+        const int cur = p & 1, nxt = cur ^ 1;
+        const double piv = prow[cur][p];
+        if (!(piv > 0.0) && threadIdx.x == 0) s_bad = 1;
+        const double ip = 1.0 / piv;
+        double fc[INV_T], pr[INV_T];
+#pragma unroll
+        for (int i = 0; i < INV_T; i++) fc[i] = fcol[cur][ty + 16 * i];
+#pragma unroll
+        for (int j = 0; j < INV_T; j++) { const int c = tx + 16 * j; pr[j] = (c == p ? 1.0 : prow[cur][c]) * ip; }
+#pragma unroll
+        for (int i = 0; i < INV_T; i++)
+#pragma unroll
+            for (int j = 0; j < INV_T; j++) {
+                const int r = ty + 16 * i, c = tx + 16 * j;
+                a[i][j] = r == p ? pr[j] : ((c == p ? 0.0 : a[i][j]) - fc[i] * pr[j]);
+                if (c == p + 1) fcol[nxt][r] = a[i][j];
+                if (r == p + 1) prow[nxt][c] = a[i][j];
+            }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < INV_B * INV_B; i += 256) D[i] = a[i / INV_B][i % INV_B];
-    if (!ok && threadIdx.x == 0) atomicOr(bad, 1);
+#pragma unroll
+    for (int i = 0; i < INV_T; i++)
+#pragma unroll
+        for (int j = 0; j < INV_T; j++) D[(ty + 16 * i) * INV_B + tx + 16 * j] = a[i][j];
+    if (threadIdx.x == 0 && s_bad) atomicOr(bad, 1);
 }
 // C (one block, in registers: thread = INV_T x INV_T outputs) = X Y with X, Y staged in LDS; k ascending
 __device__ __forceinline__ void inv_mm(const double (*X)[INV_B], const double (*Y)[INV_B], double (&c)[INV_T][INV_T])

@@ -177,7 +177,7 @@ def test_stop_flag_raised_mid_solve(ctx):
 
 def test_larger_map_widens_the_coarse_aggregates(ctx):
     """5000 keyframes / 300k points (2.7 M edges), beyond every BASELINE config: the coarse level of the preconditioner
-    switches to 32-keyframe aggregates (940 coarse unknowns instead of 1878) so that its inversion still fits inside an LM
+    switches to 32-keyframe aggregates (1099 coarse unknowns instead of 2191) so that its inversion still fits inside an LM
     trial.  No oracle at this size: chi2 must drop, no trial may fall back to the dense solver, and the run must repeat bit
     for bit."""
     g = synth.gba_graph(n_kf=5000, n_points=300000, n_agents=3, seed=5)
@@ -216,6 +216,14 @@ for kf, pts, its in ((60, 3000, 8), (240, 20000, 4)):
     assert d <= 1e-5 and r["iterations_done"] == ref["iterations_done"], (kf, d)
     strict = Optimizer.MapFusionGBA(g, its, ctx=ctx, pcg_tol=1e-13)
     assert pose_delta(strict["poses"], ref["poses"]).max() <= 1e-9
+# a stretch of keyframes that starts from ONE position: the scale columns of their aggregates vanish (the coarse unknowns stay inert),
+# and a map whose keyframes all start from one position: no scale column at all
+for lo, hi in ((100, 160), (0, 240)):
+    g = synth.gba_graph(n_kf=240, n_points=20000, n_agents=3, seed=7)
+    p = np.array(g["poses"], dtype=np.float64); p[lo:hi, 4:7] = p[lo, 4:7]; g = dict(g); g["poses"] = p
+    r = Optimizer.MapFusionGBA(g, 3, ctx=ctx, pcg_tol=1e-13); ref = O.ba_solve(g, 3, float(np.sqrt(5.99)))
+    assert r["pcg_iterations"] > 0 and r["pcg_fallbacks"] == 0, (lo, hi, r["pcg_fallbacks"])
+    assert r["trials"] == ref["trials"] and pose_delta(r["poses"], ref["poses"]).max() <= 1e-7, (lo, hi, pose_delta(r["poses"], ref["poses"]).max())
 print("ok")
 '''
     env = dict(os.environ, CCM_BA_DENSE_MAX="0", CCM_PCG_COARSE=coarse, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -671,9 +671,12 @@ __device__ __forceinline__ void pcg_block_restrict(const double* rs, int nfree, 
         const int slot = threadIdx.x / PCG_CDOF, d = threadIdx.x - PCG_CDOF * slot;
         const int I = pcg_hat(f0, A, nagg).i0 + slot;
         double s = 0.0;
-        for (int k = 0; k < PCG_UPD_KF; k++) {
-            if (ci0[k] == I) s += cw[0][k][d];
-            if (ci1[k] == I && ci1[k] != ci0[k]) s += cw[1][k][d];
+#pragma unroll 8
+        for (int k = 0; k < PCG_UPD_KF; k++) {                       // branch-free, so that the LDS reads of several keyframes are in flight (x + 0.0 == x)
+            const int j0 = ci0[k], j1 = ci1[k];
+            const double a0 = cw[0][k][d], a1 = cw[1][k][d];
+            s += j0 == I ? a0 : 0.0;
+            s += (j1 == I && j1 != j0) ? a1 : 0.0;
         }
         rpart[((long long)blockIdx.x * PCG_RSLOTS + slot) * PCG_CDOF + d] = s;
     }

@@ -485,7 +485,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
     // Chunk lengths (even: the r.z slot parity is the same at the start of every chunk): graphs of 8 and of 2 iterations; a host
     // round trip launches as many of them as the contraction observed so far says are still needed (rounded up to 2), then one
-    // publication kernel, and looks again -- with the hat-function coarse level a trial takes 20-100 iterations of 45 us, so
+    // and looks again (k_pcg_direction publishes the scalars after every iteration) -- with the hat-function coarse level a trial takes 20-100 iterations of 45 us, so
     // iterations past convergence cost more than round trips.
     const int pcg_len[2] = {8, 2};
     // Graphs: [level][length]; level 0 = the cluster level alone (first trial of a call: no coarse inverse exists yet), 1 = both levels.
@@ -691,7 +691,6 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                                                             nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pcu);
                                 }
                             }
-                            pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                             itc += last_len;
                             if (side_todo && (rc = start_inversion())) return rc;
                         }

@@ -720,24 +720,53 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(const double* __restrict__ A
     __syncthreads();
     if (threadIdx.x == 0) cpart[blockIdx.x] = ((dots[0] + dots[1]) + dots[2]) + dots[3];
 }
-// z += P yc: one thread per scalar unknown
-__global__ __launch_bounds__(256) void k_pcg_prolong(const double* __restrict__ yc, const double* __restrict__ svec, const double* __restrict__ cen,
-                                                     int nfree, int nagg, double* __restrict__ z)
+// The new search direction, one thread per scalar unknown:  p = (z + P yc) + beta p,  beta = r.z (now) / r.z (previous iteration).
+// Every workgroup re-reduces the partial sums of r.z (cluster part from k_pcg_init / k_pcg_update, coarse part from k_pcg_coarse) in
+// the same fixed order; the previous value comes from the alternating slot sc[8 + (parity ^ 1)], and block 0 leaves the current
+// one in sc[8 + parity] for k_pcg_update and the next iteration, together with the scalars the host looks at.  yc == nullptr: no
+// coarse level in this solve.
+__global__ __launch_bounds__(256) void k_pcg_direction(const double* __restrict__ yc, const double* __restrict__ svec, const double* __restrict__ cen,
+                                                       int nfree, int nagg, double* __restrict__ w, int nblk_part, const double* __restrict__ part,
+                                                       const double* __restrict__ cpart, int ncpart, double* __restrict__ sc, int parity)
 {
-    const long long o = blockIdx.x * 256LL + threadIdx.x;
-    if (o >= 6LL * nfree) return;
-    const int f = (int)(o / 6), d = (int)(o - 6LL * f);
-    const PcgHat h = pcg_hat(f, PCG_CL * pcg_agg_clusters(nfree), nagg);
-    const double* y0 = yc + PCG_CDOF * h.i0; const double* y1 = yc + PCG_CDOF * h.i1;
-    double v = h.w0 * y0[d] + h.w1 * y1[d];
-    if (d >= 3) {
-        const double t = svec[3LL * f + (d - 3)];
-        v += h.w0 * ((t - cen[3 * h.i0 + (d - 3)]) * y0[6]) + h.w1 * ((t - cen[3 * h.i1 + (d - 3)]) * y1[6]);
+    __shared__ double s_beta;
+    if (threadIdx.x < 64) {
+        double rz = 0, rr = 0;
+        for (int i = threadIdx.x; i < nblk_part; i += 64) { rz += part[3 * i]; rr += part[3 * i + 1]; }
+        double rzc = 0;
+        for (int i = threadIdx.x; i < ncpart; i += 64) rzc += cpart[i];
+        for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); rzc += __shfl_xor(rzc, st, 64); }
+        rz += rzc;
+        if (threadIdx.x == 0) {
+            const double rz_prev = sc[8 + (parity ^ 1)];
+            s_beta = rz_prev > 0.0 ? rz / rz_prev : 0.0;
+            if (blockIdx.x == 0) {                                 // scalars for k_pcg_update, the next iteration and the host
+                const double pap = part[2];
+                sc[8 + parity] = rz;
+                sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;
+            }
+        }
     }
-    z[o] += v;
+    __syncthreads();
+    const long long n = 6LL * nfree;
+    const long long o = blockIdx.x * 256LL + threadIdx.x;
+    if (o >= n) return;
+    double zf = w[2 * n + o];
+    if (yc) {
+        const int f = (int)(o / 6), d = (int)(o - 6LL * f);
+        const PcgHat h = pcg_hat(f, PCG_CL * pcg_agg_clusters(nfree), nagg);
+        const double* y0 = yc + PCG_CDOF * h.i0; const double* y1 = yc + PCG_CDOF * h.i1;
+        double v = h.w0 * y0[d] + h.w1 * y1[d];
+        if (d >= 3) {
+            const double t = svec[3LL * f + (d - 3)];
+            v += h.w0 * ((t - cen[3 * h.i0 + (d - 3)]) * y0[6]) + h.w1 * ((t - cen[3 * h.i1 + (d - 3)]) * y1[6]);
+        }
+        zf += v;
+    }
+    w[3 * n + o] = zf + s_beta * w[3 * n + o];
 }
 
-// state vector layout in `w`: x | r | z | p (even iterations) | Ap | p (odd iterations)  (each n doubles); scalars in sc[]:
+// state vector layout in `w`: x | r | z (cluster level only) | p | Ap  (each n doubles); scalars in sc[]:
 //   sc[0] rz, sc[1] |b|^2, sc[2] |r|^2, sc[3] min p.Ap seen, sc[4] iterations
 static_assert(PCG_UPD_TPB % PCG_CN == 0, "a block must hold whole clusters");
 __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restrict__ b, const double* __restrict__ Minv, int nfree,
@@ -759,7 +788,7 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_init(const double* __restri
         double z = 0;
 #pragma unroll 8
         for (int k = 0; k < PCG_CN; k++) z += M[k * PCG_CN] * rs[base + k];       // symmetric: column li read with unit stride across lanes
-        w[o] = 0.0; w[n + o] = ri; w[2 * n + o] = z; w[3 * n + o] = 0.0; w[5 * n + o] = 0.0;   // p = z + beta * 0 in the first mat-vec
+        w[o] = 0.0; w[n + o] = ri; w[2 * n + o] = z; w[3 * n + o] = 0.0;                         // p = z + beta * 0 in the first direction
         rz = ri * z; bb = ri * ri;
     }
     for (int s = 32; s >= 1; s >>= 1) { rz += __shfl_xor(rz, s, 64); bb += __shfl_xor(bb, s, 64); }
@@ -782,19 +811,12 @@ __global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ 
     sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0; sc[8] = rz; sc[9] = rz;
 }
 
-// Direction update + mat-vec in one kernel, one workgroup per block row:  p = z + beta p_old  is formed on the fly for
-// the row's own pose and for every neighbour (p_old lives in the other of two alternating buffers, so no workgroup can
-// overwrite what another still reads), then Ap = A p.  beta = r.z (this iteration) / r.z (previous): every workgroup
-// re-reduces the ~60 partial sums of k_pcg_update itself (fixed order), the previous value comes from the alternating
-// slot sc[8 + parity] and block 0 leaves the current one in the other slot for k_pcg_update and the next iteration.
+// Ap = A p, one workgroup per block row (p comes from k_pcg_direction).
 // Thread = (entry slot 0..41, row component 0..5); the 42 slot sums of a component are added in slot order by one lane.
 __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb, const int* __restrict__ row_ptr, const unsigned* __restrict__ ent_key,
-                                                  const unsigned* __restrict__ ent_val, int nfree, double* __restrict__ w, double* __restrict__ pap_part,
-                                                  int nblk_part, const double* __restrict__ part, double* __restrict__ sc, int parity,
-                                                  const double* __restrict__ cpart, int ncpart)
+                                                  const unsigned* __restrict__ ent_val, int nfree, double* __restrict__ w, double* __restrict__ pap_part)
 {
     __shared__ double red[42][6];
-    __shared__ double s_beta;
     // Workgroups are dealt round-robin to the 8 XCDs, so b and b + 8 share an L2.  Giving each XCD a contiguous range of
     // block rows means that block (i, j) of the band, needed by row i and (transposed) by row j a few rows later, is
     // fetched from the fabric once and found in that XCD's L2 the second time.
@@ -802,28 +824,7 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
     const int row = ((int)blockIdx.x % PCG_XCDS) * rows_per_xcd + (int)blockIdx.x / PCG_XCDS;
     if (row >= nfree) return;
     const long long n = 6LL * nfree;
-    if (threadIdx.x < 64) {
-        double rz = 0, rr = 0;
-        for (int i = threadIdx.x; i < nblk_part; i += 64) { rz += part[3 * i]; rr += part[3 * i + 1]; }
-        double rzc = 0;
-        for (int i = threadIdx.x; i < ncpart; i += 64) rzc += cpart[i];
-        for (int st = 32; st >= 1; st >>= 1) { rz += __shfl_xor(rz, st, 64); rr += __shfl_xor(rr, st, 64); rzc += __shfl_xor(rzc, st, 64); }
-        rz += rzc;
-        if (threadIdx.x == 0) {
-            const double rz_prev = sc[8 + parity];
-            s_beta = rz_prev > 0.0 ? rz / rz_prev : 0.0;
-            if (row == 0) {                                        // scalars for k_pcg_update, the next iteration and the host
-                const double pap = part[2];
-                sc[8 + (parity ^ 1)] = rz;
-                sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;
-            }
-        }
-    }
-    __syncthreads();
-    const double beta = s_beta;
-    const double* z = w + 2 * n;
-    const double* p_old = w + (parity ? 3 : 5) * n;
-    double* p_new = w + (parity ? 5 : 3) * n;
+    const double* p = w + 3 * n;
     const int slot = threadIdx.x / 6, r = threadIdx.x - 6 * slot;
     if (slot < 42) {
         double acc = 0;
@@ -847,11 +848,10 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
                     continue;
                 }
                 const double* B = Hb + 36 * (long long)(v[q] & 0x7FFFFFFFu);
-                const double* zc = z + 6 * (long long)col[q];
-                const double* pc = p_old + 6 * (long long)col[q];
+                const double* pc = p + 6 * (long long)col[q];
                 const bool tr = (v[q] & 0x80000000u) != 0u;
 #pragma unroll
-                for (int c = 0; c < 6; c++) { bv[q][c] = tr ? B[c * 6 + r] : B[r * 6 + c]; xv[q][c] = zc[c] + beta * pc[c]; }
+                for (int c = 0; c < 6; c++) { bv[q][c] = tr ? B[c * 6 + r] : B[r * 6 + c]; xv[q][c] = pc[c]; }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -866,10 +866,8 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(const double* __restrict__ Hb,
         if (threadIdx.x < 6) {
             for (int s2 = 0; s2 < 42; s2++) tot += red[s2][threadIdx.x];
             const long long o = 6LL * row + threadIdx.x;
-            const double pn = z[o] + beta * p_old[o];
             w[4 * n + o] = tot;
-            p_new[o] = pn;
-            pap = tot * pn;
+            pap = tot * p[o];
         }
         for (int st = 4; st >= 1; st >>= 1) pap += __shfl_xor(pap, st, 64);     // lanes 0..7 (6,7 hold 0)
         if (threadIdx.x == 0) pap_part[row] = pap;
@@ -890,8 +888,8 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
     // everything this thread needs is requested before the reduction, so that all global loads overlap
     double r_old = 0, ap = 0, x_old = 0, p_old = 0;
-    if (o < n) { r_old = w[n + o]; ap = w[4 * n + o]; x_old = w[o]; p_old = w[(parity ? 5 : 3) * n + o]; }   // this iteration's direction
-    const double rz_old = sc[8 + (parity ^ 1)];                     // this iteration's r.z, left there by k_pcg_spmv
+    if (o < n) { r_old = w[n + o]; ap = w[4 * n + o]; x_old = w[o]; p_old = w[3 * n + o]; }   // this iteration's direction
+    const double rz_old = sc[8 + (parity ^ 1)];                     // this iteration's r.z, left there by k_pcg_direction
     double s = 0;
 #pragma unroll 4
     for (int k = threadIdx.x; k < nfree; k += PCG_UPD_TPB) s += pap_part[k];
@@ -1041,14 +1039,19 @@ void pcg_launch_coarse_mirror(hipStream_t s, double* A, int ncp)
 {
     hipLaunchKernelGGL(k_pcg_coarse_mirror, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, A, ncp);
 }
-// z += P Ac^-1 P^T r  (z inside the PCG state vector w; P^T r as block partials in C.rc, left there by k_pcg_init / k_pcg_update),
-// and the coarse share of r.z into C.cpart
+// yc = Ac^-1 P^T r  (P^T r as block partials in C.rc, left there by k_pcg_init / k_pcg_update), and the coarse share of r.z into C.cpart
 static void pcg_launch_coarse(hipStream_t s, const PcgCoarse& C, int nfree, double* w)
 {
     const int nagg = pcg_coarse_aggregates(nfree), nc = PCG_CDOF * nagg;
-    const long long n = 6LL * nfree;
+    (void)w;
     hipLaunchKernelGGL(k_pcg_coarse, dim3(nblk(nc, 4)), dim3(256), (size_t)nc * 8, s, C.Aci, nc, pcg_coarse_pitch(nfree), C.rc, nfree, C.yc, C.cpart);
-    hipLaunchKernelGGL(k_pcg_prolong, dim3(nblk(n, 256)), dim3(256), 0, s, C.yc, C.svec, C.cen, nfree, nagg, w + 2 * n);
+}
+// p = (z + P yc) + beta p and the scalars of the iteration; parity = the r.z slot this call writes
+static void pcg_launch_direction(hipStream_t s, const PcgCoarse& C, int nfree, double* w, double* part, double* sc, int parity)
+{
+    const long long n = 6LL * nfree;
+    hipLaunchKernelGGL(k_pcg_direction, dim3(nblk(n, 256)), dim3(256), 0, s, C.Aci ? C.yc : nullptr, C.svec, C.cen, nfree, C.Aci ? pcg_coarse_aggregates(nfree) : 0, w,
+                       nblk(n, PCG_UPD_TPB), part, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc, parity);
 }
 void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C)
 {
@@ -1057,18 +1060,18 @@ void pcg_launch_init(hipStream_t s, const double* b, const double* Minv, int nfr
                        C.Aci ? C.rc : nullptr);
     if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
     hipLaunchKernelGGL(k_pcg_init_fin, dim3(1), dim3(64), 0, s, part, nb, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
+    pcg_launch_direction(s, C, nfree, w, part, sc, 1);          // "iteration -1": beta = r.z / r.z with p = 0, i.e. p = z + P yc
 }
-// one PCG iteration = direction + mat-vec, then the vector updates with the cluster level, then the coarse level
+// one PCG iteration = mat-vec, the vector updates with the cluster level, the coarse level, the next direction
 void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
                      int nfree, double* w, double* pap_part, double* part, double* sc, int parity, const PcgCoarse& C)
 {
     const int nb = nblk(6LL * nfree, PCG_UPD_TPB);
-    const int ncp = C.Aci ? pcg_coarse_parts(nfree) : 0;
-    hipLaunchKernelGGL(k_pcg_spmv, dim3(PCG_XCDS * nblk(nfree, PCG_XCDS)), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part, nb, part, sc, parity,
-                       C.cpart, ncp);
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(PCG_XCDS * nblk(nfree, PCG_XCDS)), dim3(256), 0, s, Hb, row_ptr, ekey, eval, nfree, w, pap_part);
     hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(PCG_UPD_TPB), 0, s, Minv, nfree, w, pap_part, sc, part, parity, C.Aci ? pcg_coarse_aggregates(nfree) : 0,
                        C.svec, C.cen, C.Aci ? C.rc : nullptr);
     if (C.Aci) pcg_launch_coarse(s, C, nfree, w);
+    pcg_launch_direction(s, C, nfree, w, part, sc, parity);
 }
 // publish the scalars of the last iteration (before the host reads them)
 void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc, const PcgCoarse& C)

@@ -888,7 +888,14 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
     // everything this thread needs is requested before the reduction, so that all global loads overlap
     double r_old = 0, ap = 0, x_old = 0, p_old = 0;
-    if (o < n) { r_old = w[n + o]; ap = w[4 * n + o]; x_old = w[o]; p_old = w[3 * n + o]; }   // this iteration's direction
+    double mv[PCG_CN];                                              // this unknown's column of its cluster inverse: 48 loads that wait for nothing
+    if (o < n) {
+        r_old = w[n + o]; ap = w[4 * n + o]; x_old = w[o]; p_old = w[3 * n + o];   // this iteration's direction
+        const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN);
+        const double* M = Minv + (long long)cl * PCG_CN * PCG_CN + li;
+#pragma unroll
+        for (int k = 0; k < PCG_CN; k++) mv[k] = M[k * PCG_CN];    // symmetric: column li read with unit stride across lanes
+    }
     const double rz_old = sc[8 + (parity ^ 1)];                     // this iteration's r.z, left there by k_pcg_direction
     double s = 0;
 #pragma unroll 4
@@ -904,11 +911,10 @@ __global__ __launch_bounds__(PCG_UPD_TPB) void k_pcg_update(const double* __rest
     pcg_block_restrict(rs, nfree, nagg, svec, cen, rpart);
     double rz = 0, rr = 0;
     if (o < n) {
-        const int cl = (int)(o / PCG_CN), li = (int)(o - (long long)cl * PCG_CN), base = (threadIdx.x / PCG_CN) * PCG_CN;
-        const double* M = Minv + (long long)cl * PCG_CN * PCG_CN + li;
+        const int base = (threadIdx.x / PCG_CN) * PCG_CN;
         double z = 0;
-#pragma unroll 8
-        for (int k = 0; k < PCG_CN; k++) z += M[k * PCG_CN] * rs[base + k];
+#pragma unroll
+        for (int k = 0; k < PCG_CN; k++) z += mv[k] * rs[base + k];
         w[o] = x_old + alpha * p_old; w[n + o] = ri; w[2 * n + o] = z;
         rz = ri * z; rr = ri * ri;
     }

@@ -135,25 +135,34 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double*
     db[3 * (long long)l + 2] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
 }
 // per edge: Y_e = Hpl_e Dinv(landmark of e)  (one thread per edge: nine times the parallelism of a loop inside k_sp_dinv)
+// Z_e = Hpl_e chol(Dinv_l)  (6 x 3; Dinv_l = C C^T, C lower triangular): then  Hpl_a Dinv Hpl_b^T = Z_a Z_b^T, and BOTH operands of
+// the Schur GEMM come from this one array.  With Y = Hpl Dinv on one side and Hpl on the other the kernel gathered from two arrays of
+// 260 MB each at config 5 -- more than the 256 MB MALL holds -- and ran at the HBM rate of its line-granular gathers (3.7 GB of fabric
+// reads per launch, 4.5 TB/s); one array halves the working set.
 __global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double* __restrict__ Y)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= D.E) return;
     const double* Di = D.Dinv + 9 * (long long)D.edge_point[e];
-    const double d0 = Di[0], d1 = Di[1], d2 = Di[2], d3 = Di[3], d4 = Di[4], d5 = Di[5], d6 = Di[6], d7 = Di[7], d8 = Di[8];
+    // Cholesky of the symmetric positive definite 3 x 3 inverse (upper half of Di read)
+    const double c00 = sqrt(Di[0]);
+    const double c10 = Di[1] / c00, c20 = Di[2] / c00;
+    const double c11 = sqrt(Di[4] - c10 * c10);
+    const double c21 = (Di[5] - c20 * c10) / c11;
+    const double c22 = sqrt(Di[8] - c20 * c20 - c21 * c21);
     const double* B = D.Hpl + 18 * (long long)e;
     double* y = Y + 18 * (long long)e;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const double x = B[i * 3], yy = B[i * 3 + 1], z = B[i * 3 + 2];
-        y[i * 3] = x * d0 + yy * d3 + z * d6;
-        y[i * 3 + 1] = x * d1 + yy * d4 + z * d7;
-        y[i * 3 + 2] = x * d2 + yy * d5 + z * d8;
+        y[i * 3] = x * c00 + yy * c10 + z * c20;
+        y[i * 3 + 1] = yy * c11 + z * c21;
+        y[i * 3 + 2] = z * c22;
     }
 }
 
-// One workgroup per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Y_a W_b^T
-// with Y_a = Hpl_a Dinv (6x3) and W_b = Hpl_b (6x3).  The sum over pairs is one GEMM with K = 3 x pairs:
+// One workgroup per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Z_a Z_b^T
+// with Z_e = Hpl_e chol(Dinv) (6x3, k_sp_edge_y; the argument Y is that array).  The sum over pairs is one GEMM with K = 3 x pairs:
 // [Y_a1 Y_a2 ...] (6 x K) times [W_b1 W_b2 ...]^T (K x 6), run on the f64 matrix cores as v_mfma_f64_16x16x4_f64
 // (M = N = 16 of which 6 are used, K = 4 per instruction: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]).
 // Four pairs = twelve k = three MFMAs per step (eight pairs per step measured slower); each lane gathers exactly the operand
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
             av[m] = 0.0; bv[m] = 0.0;
             if (pr[m] != NONE) {
                 av[m] = Y[18 * (long long)(unsigned)(pr[m] >> 32) + 3 * i + cl[m]];
-                bv[m] = D.Hpl[18 * (long long)(unsigned)(pr[m] & 0xFFFFFFFFu) + 3 * i + cl[m]];
+                bv[m] = Y[18 * (long long)(unsigned)(pr[m] & 0xFFFFFFFFu) + 3 * i + cl[m]];
             }
         }
     };

@@ -357,7 +357,7 @@ def main():
             if rp["pcg_iterations"]:
                 per_it = rp["t_solve"] / rp["pcg_iterations"]
                 spmv_bytes = (2 * r["schur_blocks"] - 1999) * 288.0
-                roof["solve"] = {"kernels": "k_pcg_spmv + k_pcg_update + k_pcg_coarse + k_pcg_prolong (HIP graphs)", "bound": "hbm",
+                roof["solve"] = {"kernels": "k_pcg_spmv + k_pcg_update + k_pcg_coarse + k_pcg_direction (HIP graphs)", "bound": "hbm",
                                  "us_per_pcg_iteration_host_timed": round(per_it * 1e6, 2),
                                  "spmv_algorithmic_bytes": int(spmv_bytes), "achieved": round(spmv_bytes / per_it / 1e9, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(spmv_bytes / per_it / 1e9 / HBM_PEAK_GBS, 5),

@@ -26,7 +26,7 @@ Hs = sp.triu(Hs) + sp.triu(Hs, 1).T          # the oracle fills the upper block 
 Hs = Hs.tocsr()
 print("reduced system: n = %d, nnz = %d" % (n, Hs.nnz))
 poses = np.asarray(g["poses"]); free = np.where(np.asarray(g["fixed"]) == 0)[0]
-CL, AGG = 8, 2                                 # keyframes per cluster, clusters per aggregate
+CL, AGG = int(os.environ.get("STUDY_CL", "8")), 2
 ncl = (nf + CL - 1) // CL; nagg = (ncl + AGG - 1) // AGG
 # cluster level
 Minv = []

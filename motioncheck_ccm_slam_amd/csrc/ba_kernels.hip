@@ -310,11 +310,12 @@ void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial,
     if (nb > 0) hipLaunchKernelGGL(k_ba_errors, dim3(nb), dim3(256), 0, s, D, hd, partial);
     hipLaunchKernelGGL(k_ba_reduce, dim3(1), dim3(256), 0, s, partial, nb, out, 0);
 }
-#define BA_SMALL_MAP_LANDMARKS 32768      // up to here eight lanes share a landmark (see k_ba_lin_landmark)
+#ifndef BA_LM_LANES
+#define BA_LM_LANES 8                     // lanes that share a landmark in k_ba_lin_landmark / k_ba_backsub (measured: see DESIGN.md)
+#endif
 void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
 {
-    if (D.L > 0 && D.L <= BA_SMALL_MAP_LANDMARKS) hipLaunchKernelGGL(k_ba_lin_landmark<8>, dim3(nblk(8LL * D.L, 256)), dim3(256), 0, s, D, hd);
-    else if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark<1>, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark<BA_LM_LANES>, dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
     // few keyframes with long edge lists (local BA): a workgroup per keyframe; maps with thousands of keyframes: a wave each (measured:
     // the workgroup form costs config 5 another 60 us per linearisation, the wave form costs config 4 40 us)
     // (16 waves per keyframe measured no faster than 4 at 20 keyframes x 1300 edges: 22.1 against 21.1 us -- the keyframe's edges are
@@ -324,8 +325,7 @@ void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
 }
 void ba_launch_backsub(hipStream_t s, const BaDev& D)
 {
-    if (D.L > 0 && D.L <= BA_SMALL_MAP_LANDMARKS) hipLaunchKernelGGL(k_ba_backsub<8>, dim3(nblk(8LL * D.L, 256)), dim3(256), 0, s, D);
-    else if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub<1>, dim3(nblk(D.L, 256)), dim3(256), 0, s, D);
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub<BA_LM_LANES>, dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D);
 }
 void ba_launch_update(hipStream_t s, const BaDev& D)
 {

@@ -304,11 +304,19 @@ def main():
                     D.init_comm(ctx, rank, world)
             g = synth.gba_graph()
             E = len(g["edge_pose"])
+            # the map's edge arrays are page-locked once, as a server that keeps its graph buffers would (ccm_host_register);
+            # three timed calls, the median is reported (pageable uploads were seen to take 1.5 or 19 ms from call to call)
+            for k in ("edge_pose", "edge_point", "obs", "info"):
+                ctx.host_register(g[k])
             Optimizer.MapFusionGBA(g, 1, ctx=ctx)                       # warm-up (allocations, graph capture)
             fence()
-            tg = time.perf_counter()
-            r = Optimizer.MapFusionGBA(g, args.gba_iters, ctx=ctx)
-            call_s = time.perf_counter() - tg
+            calls = []
+            for _ in range(3):
+                tg = time.perf_counter()
+                r = Optimizer.MapFusionGBA(g, args.gba_iters, ctx=ctx)
+                calls.append((time.perf_counter() - tg, r))
+            calls.sort(key=lambda c: c[0])
+            call_s, r = calls[1]
             lm_s = r["t_linearize"] + r["t_schur"] + r["t_solve"] + r["t_update"]
             if world > 1:
                 t = torch.tensor([lm_s, call_s], dtype=torch.float64, device=red_dev)
@@ -320,9 +328,10 @@ def main():
                    "iter_per_s": round(r["iterations_done"] / call_s, 3),
                    "iter_per_s_lm_loop_only": round(r["iterations_done"] / lm_s, 3),
                    "iterations": r["iterations_done"], "iterations_requested": args.gba_iters, "trials": r["trials"],
-                   "call_seconds": round(call_s, 4), "lm_seconds": round(lm_s, 4),
+                   "call_seconds": round(call_s, 4), "call_seconds_all": [round(c[0], 4) for c in calls], "timed_calls": "3, median reported",
+                   "lm_seconds": round(lm_s, 4),
                    "setup_seconds": round(call_s - lm_s, 4),
-                   "setup_note": "graph upload, pair enumeration, radix sort, block pattern, PCG graph capture, result download",
+                   "setup_note": "graph upload (edge arrays page-locked by the caller), pair enumeration, radix sort, block pattern, PCG graph capture, result download",
                    "t_linearize": round(r["t_linearize"], 4), "t_schur": round(r["t_schur"], 4),
                    "t_solve": round(r["t_solve"], 4), "t_update": round(r["t_update"], 4),
                    "ms_per_iteration_lm": round(lm_s / its * 1e3, 3),
@@ -386,6 +395,8 @@ def main():
                                        "sample": "config 5 itself (2000 KF / 200k points / %d edges), 2 LM iterations of the oracle incl. its one-off "
                                                  "minimum-degree ordering; reduced solve = block-sparse Cholesky (sparse + exact like g2o's "
                                                  "LinearSolverEigen), chi2 after 2 iterations %.6e" % (E, rc["chi2_final"])}
+            for k in ("edge_pose", "edge_point", "obs", "info"):
+                ctx.host_unregister(g[k])
             gba_box["gba"] = gba
         except Exception as e:  # the headline number must survive a communicator problem
             gba_box["gba"] = {"error": "%s: %s" % (type(e).__name__, e)}

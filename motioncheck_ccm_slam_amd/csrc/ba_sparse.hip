@@ -178,18 +178,26 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
                                                          const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb,
                                                          double* __restrict__ Hb)
 {
-    __shared__ double part[NWV][36];
+    // TWO reduced blocks per workgroup share the 16 x 16 tile of the MFMA: operand rows 0..5 belong to block 2 g, rows 8..13 to block
+    // 2 g + 1 (each with its own pair list), and the tile's two diagonal 6 x 6 corners are the two sums (the off-diagonal corners mix the
+    // blocks and are dropped).  The same number of gather loads now serves two blocks: 48 of 64 lanes load instead of 24.
+    __shared__ double part[NWV][72];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x;
-    const int i = lane & 15, kq = lane >> 4;                // operand row (< 6 used), k within an MFMA
-    const int p0 = seg_start[b], p1 = seg_end[b];
+    const int i16 = lane & 15, kq = lane >> 4;              // operand row of the tile, k within an MFMA
+    const int half = i16 >> 3, i = i16 & 7;                 // which of the two blocks, row inside it (< 6 used)
+    const int b = 2 * (int)blockIdx.x + half;
+    const bool live = i < 6 && b < nb;
+    const int p0 = live ? seg_start[b] : 0, p1 = live ? seg_end[b] : 0;
+    // the longer of the workgroup's two lists sets the trip count (wave-uniform)
+    int pmax = p1 - p0;
+    for (int st = 32; st >= 1; st >>= 1) pmax = max(pmax, __shfl_xor(pmax, st, 64));
     sp_v4d acc = { 0.0, 0.0, 0.0, 0.0 };
     // The twelve k of a step: k = 4 m + kq is column m of pair kq -- a lane's three operand elements are one row of ONE pair's block:
     // one pair index and 24 contiguous bytes per operand (a dwordx4 and a dwordx2), instead of three indices and three scattered
     // doubles.  The kernel's rate is set by its gather requests: 5 loads per step instead of 9.
     const unsigned long long NONE = ~0ull;
     typedef double sp_d2u __attribute__((ext_vector_type(2), aligned(8)));
-    auto ld_idx = [&](int p) -> unsigned long long { return (i < 6 && p + kq < p1) ? pairs[p + kq] : NONE; };
+    auto ld_idx = [&](int q) -> unsigned long long { return (live && p0 + q + kq < p1) ? pairs[p0 + q + kq] : NONE; };   // q = offset into the list
     auto ld_ops = [&](unsigned long long pr, double (&av)[3], double (&bv)[3]) {
         av[0] = av[1] = av[2] = 0.0; bv[0] = bv[1] = bv[2] = 0.0;
         if (pr != NONE) {
@@ -202,34 +210,37 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
     };
     unsigned long long pr_next, pr_far;
     double av[3], bv[3], av_next[3], bv_next[3];
-    int p = p0 + 4 * wv;                                    // this wave's steps: 4 pairs each, 4 NWV pairs apart
-    pr_next = ld_idx(p); ld_ops(pr_next, av, bv); pr_next = ld_idx(p + 4 * NWV);
-    for (; p < p1; p += 4 * NWV) {
+    int q = 4 * wv;                                         // this wave's steps: 4 pairs each, 4 NWV pairs apart
+    pr_next = ld_idx(q); ld_ops(pr_next, av, bv); pr_next = ld_idx(q + 4 * NWV);
+    for (; q < pmax; q += 4 * NWV) {
         ld_ops(pr_next, av_next, bv_next);
-        pr_far = ld_idx(p + 8 * NWV);
+        pr_far = ld_idx(q + 8 * NWV);
 #pragma unroll
         for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[m], acc, 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < 3; m++) { av[m] = av_next[m]; bv[m] = bv_next[m]; }
         pr_next = pr_far;
     }
-    // C/D: column = lane & 15, row = (lane >> 4) + 4 * reg
-    const int c = lane & 15;
+    // C/D: column = lane & 15, row = (lane >> 4) + 4 * reg; block `half` sits in rows and columns 8 half .. 8 half + 5
+    const int c = i16 & 7;
     if (c < 6) {
 #pragma unroll
-        for (int reg = 0; reg < 2; reg++) {
-            const int r = kq + 4 * reg;
-            if (r < 6) part[wv][6 * r + c] = acc[reg];
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = kq + 4 * reg;
+            if ((row >> 3) == half && (row & 7) < 6) part[wv][36 * half + 6 * (row & 7) + c] = acc[reg];
         }
     }
     __syncthreads();
-    if (threadIdx.x < 36) {
-        const int rb = blk_row[b], cb = blk_col[b];
-        const double base = rb == cb ? D.Hpp[36 * (long long)rb + threadIdx.x] : 0.0;
-        double tot = part[0][threadIdx.x];
+    if (threadIdx.x < 72) {
+        const int h2 = threadIdx.x / 36, e = threadIdx.x - 36 * h2, bb = 2 * (int)blockIdx.x + h2;
+        if (bb < nb) {
+            const int rb = blk_row[bb], cb = blk_col[bb];
+            const double base = rb == cb ? D.Hpp[36 * (long long)rb + e] : 0.0;
+            double tot = part[0][threadIdx.x];
 #pragma unroll
-        for (int w2 = 1; w2 < NWV; w2++) tot += part[w2][threadIdx.x];                                  // wave 0 .. NWV-1: fixed order
-        Hb[36 * (long long)b + threadIdx.x] = base - tot;
+            for (int w2 = 1; w2 < NWV; w2++) tot += part[w2][threadIdx.x];                              // wave 0 .. NWV-1: fixed order
+            Hb[36 * (long long)bb + e] = base - tot;
+        }
     }
 }
 
@@ -1012,8 +1023,8 @@ void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, cons
 {
     // few blocks with long pair lists (a local BA: 210 blocks of ~1000 pairs) get 16 waves per block, maps with many blocks 4
     if (nb <= 0) return;
-    if (nb < 2048) hipLaunchKernelGGL(k_sp_schur_blocks<16>, dim3(nb), dim3(1024), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
-    else hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3(nb), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
+    if (nb < 2048) hipLaunchKernelGGL(k_sp_schur_blocks<16>, dim3((nb + 1) / 2), dim3(1024), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
+    else hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3((nb + 1) / 2), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
 }
 void sp_launch_bschur(hipStream_t s, const BaDev& D, const double* db, double* bs)
 {

@@ -481,7 +481,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         PC.svec = S.pcg_svec.as<double>();
         PC.cen = PC.svec + 3 * (size_t)nfree;
     }
-    // The PCG inner loop is two small dependent kernels per iteration and is launch-bound when issued one by
+    // The PCG inner loop is three or four small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
     // Chunk lengths (even: the r.z slot parity is the same at the start of every chunk): graphs of 8 and of 2 iterations; a host
     // round trip launches as many of them as the contraction observed so far says are still needed (rounded up to 2), then one

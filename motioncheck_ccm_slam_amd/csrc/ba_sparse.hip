@@ -135,34 +135,35 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double*
     db[3 * (long long)l + 2] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
 }
 // per edge: Y_e = Hpl_e Dinv(landmark of e)  (one thread per edge: nine times the parallelism of a loop inside k_sp_dinv)
-// Z_e = Hpl_e chol(Dinv_l)  (6 x 3; Dinv_l = C C^T, C lower triangular): then  Hpl_a Dinv Hpl_b^T = Z_a Z_b^T, and BOTH operands of
-// the Schur GEMM come from this one array.  With Y = Hpl Dinv on one side and Hpl on the other the kernel gathered from two arrays of
-// 260 MB each at config 5 -- more than the 256 MB MALL holds -- and ran at the HBM rate of its line-granular gathers (3.7 GB of fabric
-// reads per launch, 4.5 TB/s); one array halves the working set.
-__global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double* __restrict__ Y)
+// Z_e = Hpl_e L^-T  (6 x 3) with Hll + lambda I = L L^T (Cholesky of the landmark's damped 3 x 3 block): Dinv = L^-T L^-1, so
+// Hpl_a Dinv Hpl_b^T = Z_a Z_b^T, and BOTH operands of the Schur GEMM come from this one array.  With Y = Hpl Dinv on one side and
+// Hpl on the other the kernel gathered from two arrays of 260 MB each at config 5 -- more than the 256 MB MALL holds; one array
+// halves the working set.  (The factor is taken of the block itself, not of its computed inverse: three square roots of pivots that
+// are positive whenever the block is.)
+__global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double lambda, double* __restrict__ Y)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= D.E) return;
-    const double* Di = D.Dinv + 9 * (long long)D.edge_point[e];
-    // Cholesky of the symmetric positive definite 3 x 3 inverse (upper half of Di read)
-    const double c00 = sqrt(Di[0]);
-    const double c10 = Di[1] / c00, c20 = Di[2] / c00;
-    const double c11 = sqrt(Di[4] - c10 * c10);
-    const double c21 = (Di[5] - c20 * c10) / c11;
-    const double c22 = sqrt(Di[8] - c20 * c20 - c21 * c21);
+    const double* H = D.Hll + 9 * (long long)D.edge_point[e];
+    // lower Cholesky factor of H + lambda I (upper half of H read)
+    const double l00 = sqrt(H[0] + lambda), i00 = 1.0 / l00;
+    const double l10 = H[1] * i00, l20 = H[2] * i00;
+    const double l11 = sqrt((H[4] + lambda) - l10 * l10), i11 = 1.0 / l11;
+    const double l21 = (H[5] - l20 * l10) * i11;
+    const double i22 = 1.0 / sqrt((H[8] + lambda) - l20 * l20 - l21 * l21);
     const double* B = D.Hpl + 18 * (long long)e;
     double* y = Y + 18 * (long long)e;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const double x = B[i * 3], yy = B[i * 3 + 1], z = B[i * 3 + 2];
-        y[i * 3] = x * c00 + yy * c10 + z * c20;
-        y[i * 3 + 1] = yy * c11 + z * c21;
-        y[i * 3 + 2] = z * c22;
+    for (int i = 0; i < 6; i++) {                               // row z of Z solves z L^T = w
+        const double z0 = B[i * 3] * i00;
+        const double z1 = (B[i * 3 + 1] - z0 * l10) * i11;
+        const double z2 = (B[i * 3 + 2] - z0 * l20 - z1 * l21) * i22;
+        y[i * 3] = z0; y[i * 3 + 1] = z1; y[i * 3 + 2] = z2;
     }
 }
 
 // One workgroup per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Z_a Z_b^T
-// with Z_e = Hpl_e chol(Dinv) (6x3, k_sp_edge_y; the argument Y is that array).  The sum over pairs is one GEMM with K = 3 x pairs:
+// with Z_e = Hpl_e L^-T, Hll + lambda I = L L^T (6x3, k_sp_edge_y; the argument Y is that array).  The sum over pairs is one GEMM with K = 3 x pairs:
 // [Y_a1 Y_a2 ...] (6 x K) times [W_b1 W_b2 ...]^T (K x 6), run on the f64 matrix cores as v_mfma_f64_16x16x4_f64
 // (M = N = 16 of which 6 are used, K = 4 per instruction: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]).
 // Four pairs = twelve k = three MFMAs per step (eight pairs per step measured slower); each lane gathers exactly the operand
@@ -1016,7 +1017,7 @@ void sp_launch_row_ptr(hipStream_t s, const unsigned* skey, int n_ent, int nfree
 void sp_launch_dinv(hipStream_t s, const BaDev& D, double lambda, double* Y, double* db)
 {
     if (D.L > 0) hipLaunchKernelGGL(k_sp_dinv, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, lambda, Y, db);
-    if (D.E > 0) hipLaunchKernelGGL(k_sp_edge_y, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, Y);
+    if (D.E > 0) hipLaunchKernelGGL(k_sp_edge_y, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, lambda, Y);
 }
 void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, const unsigned long long* pairs, const int* st, const int* en,
                             const int* br, const int* bc, int nb, double* Hb)

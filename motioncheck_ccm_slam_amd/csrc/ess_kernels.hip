@@ -118,12 +118,29 @@ __global__ __launch_bounds__(256) void k_essp_factor(const int* __restrict__ col
     if (tid < 49) {
         const int r = tid / 7, c2 = tid - 7 * r;
         double a = D[49LL * j + tid] + (r == c2 ? lambda : 0.0);
-        for (int k = tptr[j]; k < tptr[j + 1]; k++) {
-            const double* A = Lb + 49LL * tpa[k] + 7 * r; const double* B = Lb + 49LL * tpb[k] + 7 * c2;
-            double v = 0;
+        // the update terms in list order, four at a time: their index loads are issued together, then their block rows (a late round's
+        // column has 60-100 terms; one after the other they were 60-100 dependent round trips, 70 us per round)
+        const int k1 = tptr[j + 1];
+        for (int k = tptr[j]; k < k1; k += 4) {
+            int ia[4], ib[4];
 #pragma unroll
-            for (int q = 0; q < 7; q++) v += A[q] * B[q];
-            a -= v;
+            for (int u = 0; u < 4; u++) { const int kk = min(k + u, k1 - 1); ia[u] = tpa[kk]; ib[u] = tpb[kk]; }
+            double va[4][7], vb[4][7];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double* A = Lb + 49LL * ia[u] + 7 * r; const double* B = Lb + 49LL * ib[u] + 7 * c2;
+#pragma unroll
+                for (int q = 0; q < 7; q++) { va[u][q] = A[q]; vb[u][q] = B[q]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k + u < k1) {
+                    double v = 0;
+#pragma unroll
+                    for (int q = 0; q < 7; q++) v += va[u][q] * vb[u][q];
+                    a -= v;
+                }
+            }
         }
         Ljj[tid] = a;
     }
@@ -153,17 +170,31 @@ __global__ __launch_bounds__(256) void k_essp_factor(const int* __restrict__ col
 #pragma unroll
         for (int q = 0; q < 7; q++) row[q] = Lb[49LL * s + 7 * r + q];
         const int t = ncol + s;
-        for (int k = tptr[t]; k < tptr[t + 1]; k++) {
-            const double* A = Lb + 49LL * tpa[k] + 7 * r; const double* B = Lb + 49LL * tpb[k];
-            double av[7];
+        const int k1 = tptr[t + 1];
+        for (int k = tptr[t]; k < k1; k += 2) {                       // two terms at a time (index loads, then rows, then sums; list order kept)
+            int ia[2], ib[2];
 #pragma unroll
-            for (int q = 0; q < 7; q++) av[q] = A[q];
+            for (int u = 0; u < 2; u++) { const int kk = min(k + u, k1 - 1); ia[u] = tpa[kk]; ib[u] = tpb[kk]; }
+            double av[2][7], bv[2][49];
 #pragma unroll
-            for (int c2 = 0; c2 < 7; c2++) {
-                double v = 0;
+            for (int u = 0; u < 2; u++) {
+                const double* A = Lb + 49LL * ia[u] + 7 * r; const double* B = Lb + 49LL * ib[u];
 #pragma unroll
-                for (int q = 0; q < 7; q++) v += av[q] * B[7 * c2 + q];
-                row[c2] -= v;
+                for (int q = 0; q < 7; q++) av[u][q] = A[q];
+#pragma unroll
+                for (int q = 0; q < 49; q++) bv[u][q] = B[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (k + u < k1) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 7; c2++) {
+                        double v = 0;
+#pragma unroll
+                        for (int q = 0; q < 7; q++) v += av[u][q] * bv[u][7 * c2 + q];
+                        row[c2] -= v;
+                    }
+                }
             }
         }
 #pragma unroll

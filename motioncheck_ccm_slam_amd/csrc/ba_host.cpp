@@ -172,9 +172,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         (pb->n_points > 0 && !pb->points) || (pb->n_edges > 0 && (!pb->edge_pose || !pb->edge_point || !pb->obs || !pb->info)))
         return ccm_fail(c, CCM_E_ARG, "bad BA problem");
     const int P = pb->n_poses, Lall = pb->n_points, Eall = pb->n_edges;
-    for (int e = 0; e < Eall; e++)
-        if (pb->edge_pose[e] < 0 || pb->edge_pose[e] >= P || pb->edge_point[e] < 0 || pb->edge_point[e] >= Lall)
-            return ccm_fail(c, CCM_E_ARG, "edge %d references a vertex out of range", e);
+    // (every edge's vertex indices are range-checked by the first pass over the edge list below, before anything indexes with them)
     CCM_HIP(c, hipSetDevice(c->device));
     if (!c->ba) c->ba = new BaState();
     BaState& S = *c->ba;
@@ -214,7 +212,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     int l0 = 0, l1 = Lall;
     if (ranks > 1) {
         std::vector<int32_t> cut(ranks + 1);
-        ccm_ba_landmark_cuts(pb->edge_point, Eall, Lall, ranks, cut.data());
+        if (ccm_ba_landmark_cuts(pb->edge_point, Eall, Lall, ranks, cut.data())) return ccm_fail(c, CCM_E_ARG, "an edge references a landmark out of range");
         l0 = cut[rank]; l1 = cut[rank + 1];
     }
     const int L = l1 - l0;
@@ -238,19 +236,23 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     int n_local = 0;
     {
         std::vector<int> cnt(NT, 0), bad(NT, 0), first_l(NT, -1), first_p(NT, -1), last_l(NT, -1), last_p(NT, -1);
+        std::vector<long long> out_of_range(NT, -1);
         pfor([&](int t) {
             const auto r = slice(Eall, t);
             int prev_l = -1, prev_p = -1, c = 0, b = 0;
             for (long long e = r.first; e < r.second; e++) {
                 const int l = pb->edge_point[e];
-                if (l < l0 || l >= l1) continue;
                 const int p = pb->edge_pose[e];
+                if (p < 0 || p >= P || l < 0 || l >= Lall) { if (out_of_range[t] < 0) out_of_range[t] = e; continue; }
+                if (l < l0 || l >= l1) continue;
                 if (c == 0) { first_l[t] = l; first_p[t] = p; }
                 else if (l < prev_l || (l == prev_l && p < prev_p)) b = 1;
                 prev_l = l; prev_p = p; c++;
             }
             cnt[t] = c; bad[t] = b; last_l[t] = prev_l; last_p[t] = prev_p;
         });
+        for (int t = 0; t < NT; t++)
+            if (out_of_range[t] >= 0) return ccm_fail(c, CCM_E_ARG, "edge %lld references a vertex out of range", out_of_range[t]);
         int pl = -1, pp = -1;
         for (int t = 0; t < NT; t++) {
             if (bad[t]) sorted = false;

@@ -84,3 +84,19 @@ def test_bundle_adjustment_with_no_landmarks_or_no_edges(ctx):
     no_edges = dict(g, edge_pose=np.zeros(0, "i4"), edge_point=np.zeros(0, "i4"), obs=np.zeros((0, 2)), info=np.zeros(0))
     r = Optimizer.BundleAdjustmentClient(no_edges, 3, ctx=ctx)
     assert (r["poses"] == g["poses"]).all() and (r["points"] == g["points"]).all()
+
+
+@pytest.mark.gpu
+def test_ba_rejects_edges_out_of_range(ctx):
+    """An edge that names a keyframe or a landmark that does not exist is an argument error, on small and on large
+    (multi-threaded index pass) graphs."""
+    from motioncheck_ccm_slam_amd import _lib, synth
+    from motioncheck_ccm_slam_amd.optimizer import Optimizer
+    for kf, pts in ((30, 1500), (600, 120000)):
+        g = dict(synth.gba_graph(n_kf=kf, n_points=pts, n_agents=3, seed=3))
+        for key, bad in (("edge_pose", kf), ("edge_point", -1)):
+            h = dict(g); a = np.array(g[key]); a[len(a) // 2] = bad; h[key] = a
+            with pytest.raises(_lib.CcmError):
+                Optimizer.MapFusionGBA(h, 2, ctx=ctx)
+        r = Optimizer.MapFusionGBA(g, 2, ctx=ctx)                  # the context is still usable
+        assert r["chi2_final"] < r["chi2_initial"]

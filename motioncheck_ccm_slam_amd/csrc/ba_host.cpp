@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <memory>
 #include <numeric>
 #include <thread>
 
@@ -308,7 +309,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     const double* e_info = direct ? pb->info : e_info_v.data();
     // pt_first: the edges are sorted by landmark, so a landmark's first edge is where the landmark index changes;
     // pose_edges: stable counting sort of the edges by free keyframe, slice by slice
-    std::vector<int> pose_first(nfree + 1, 0), pose_edges;
+    std::vector<int> pose_first(nfree + 1, 0);
+    std::unique_ptr<int[]> pose_edges;                        // every slot is written below: no zero-fill of 7 MB
+    size_t n_pose_edges = 0;
     {
         std::vector<std::vector<int>> hist(NT, std::vector<int>(nfree + 1, 0));
         pfor([&](int t) {
@@ -331,7 +334,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
             for (int t = 0; t < NT; t++) { const int c = hist[t][f]; hist[t][f] = acc; acc += c; }
         }
         pose_first[nfree] = acc;
-        pose_edges.resize(acc);
+        n_pose_edges = (size_t)acc; pose_edges.reset(new int[std::max<size_t>(n_pose_edges, 1)]);
         pfor([&](int t) {
             const auto r = slice(E, t);
             std::vector<int>& fill = hist[t];
@@ -353,7 +356,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     if ((rc = upload(c, S.info, e_info, E))) return rc;
     if ((rc = upload(c, S.pt_first, pt_first.data(), L + 1))) return rc;
     if ((rc = upload(c, S.pose_first, pose_first.data(), nfree + 1))) return rc;
-    if ((rc = upload(c, S.pose_edges, pose_edges.data(), pose_edges.size()))) return rc;
+    if ((rc = upload(c, S.pose_edges, pose_edges.get(), n_pose_edges))) return rc;
     const size_t nxl = (size_t)n + 3 * (size_t)L;
     CCM_RESERVE(c, S.Rt, 12 * (size_t)P * 8);
     CCM_RESERVE(c, S.active, std::max<size_t>(E, 16)); CCM_RESERVE(c, S.flags, std::max<size_t>(E, 16));

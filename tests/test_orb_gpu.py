@@ -53,6 +53,7 @@ def test_batch_every_stage(ctx, oracle):
     (752, 480, 500, 1.5, 5, 30, 10),       # other scale factor / thresholds
     (1241, 376, 1500, 1.2, 8, 20, 7),      # KITTI aspect ratio: 4 quadtree roots
     (752, 480, 1000, 1.2, 8, 7, 20),       # iniTh < minTh (degenerate but legal)
+    (1920, 1080, 3000, 1.2, 8, 20, 7),     # full HD: 64 x 36 cells on level 0, 625-feature quota
 ])
 def test_parameter_sweep(ctx, oracle, w, h, nf, sf, nl, ini, mn):
     ex = ORBextractor(nf, sf, nl, ini, mn, ctx=ctx)

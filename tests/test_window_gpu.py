@@ -85,7 +85,7 @@ def test_search_by_projection_frame_to_frame(ctx, oracle, check_ori):
     has_obs = rng.random(n_last) < 0.9                             # a few map points without observations: overwrites happen
     occupied = np.zeros(len(k2), bool)
     m = ORBmatcher(0.9, check_ori, ctx=ctx)
-    for th in (7.0, 15.0):
+    for th in (7.0, 15.0, 40.0):                                   # 40: far more candidates per point than the 16 a thread keeps in registers
         nm, match, occ = m.SearchByProjectionFrame(cur, k2["angle"], sf, valid, u, v, k1["octave"], k1["angle"], d1, has_obs, occupied, th)
         rn, rmatch, rocc = oracle.search_by_projection_frame(cur.kx, cur.ky, cur.oct, d2, k2["angle"], cur.min_x, cur.min_y, cur.inv_w, cur.inv_h,
                                                              sf, valid, u, v, k1["octave"], k1["angle"], d1, has_obs, occupied, th, check_ori)

@@ -331,7 +331,7 @@ def main():
                    "call_seconds": round(call_s, 4), "call_seconds_all": [round(c[0], 4) for c in calls], "timed_calls": "3, median reported",
                    "lm_seconds": round(lm_s, 4),
                    "setup_seconds": round(call_s - lm_s, 4),
-                   "setup_note": "graph upload (edge arrays page-locked by the caller), pair enumeration, radix sort, block pattern, PCG graph capture, result download",
+                   "setup_note": "graph upload (edge arrays page-locked by the caller), edge-list check and index on the device, pair enumeration, radix sorts, block pattern, PCG graph capture, result download",
                    "t_linearize": round(r["t_linearize"], 4), "t_schur": round(r["t_schur"], 4),
                    "t_solve": round(r["t_solve"], 4), "t_update": round(r["t_update"], 4),
                    "ms_per_iteration_lm": round(lm_s / its * 1e3, 3),

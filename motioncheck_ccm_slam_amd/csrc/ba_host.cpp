@@ -69,6 +69,9 @@ int pcg_coarse_pitch(int nfree);
 int dense_pitch(long long n);
 void dense_launch_solve(hipStream_t, double* A, int n, int lda, const double* b, double* x, int* bad);
 void ba_launch_backsub(hipStream_t, const BaDev&);
+void ba_launch_index_check(hipStream_t, const int* edge_pose, const int* edge_point, int E, int P, int L, int* flags, int* pt_first);
+void ba_launch_index_pose_keys(hipStream_t, const int* edge_pose, const int* free_of, int E, int P, int nfree, unsigned* key, unsigned* val);
+void ba_launch_index_pose_first(hipStream_t, const unsigned* skey, int E, int nfree, int* pose_first);
 void ba_launch_update(hipStream_t, const BaDev&);
 int ba_scale_blocks(const BaDev&);
 void ba_launch_scale(hipStream_t, const BaDev&, double lambda, int add_pose_lambda, double* partial, double* out);
@@ -232,10 +235,38 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         for (auto& x : th) x.join();
     };
     auto slice = [&](long long total, int t) { return std::pair<long long, long long>(total * t / NT, total * (t + 1) / NT); };
+    // Large unsharded maps: the raw edge list goes up as it is, and the device checks it (vertex ranges, order) and makes the index
+    // structures (landmark -> edges, free keyframe -> edges by a stable radix sort).  A list that turns out unsorted takes the host path.
+    int rc;
+    bool dev_indexed = false;
+    static const bool host_index_only = getenv("CCM_BA_HOST_INDEX") && atoi(getenv("CCM_BA_HOST_INDEX")) != 0;
+    if (ranks == 1 && Eall >= 400000 && nfree > 0 && Lall > 0 && !host_index_only) {
+        if ((rc = upload(c, S.free_of, free_of.data(), P))) return rc;
+        if ((rc = upload(c, S.edge_pose, pb->edge_pose, Eall))) return rc;
+        if ((rc = upload(c, S.edge_point, pb->edge_point, Eall))) return rc;
+        CCM_RESERVE(c, S.pt_first, ((size_t)Lall + 2) * 4); CCM_RESERVE(c, S.pose_first, ((size_t)nfree + 2) * 4);
+        CCM_RESERVE(c, S.pose_edges, (size_t)Eall * 4 + 16); CCM_RESERVE(c, S.info_dev, 64);
+        CCM_RESERVE(c, S.sp_key, (size_t)Eall * 4 + 16); CCM_RESERVE(c, S.sp_key2, (size_t)Eall * 4 + 16); CCM_RESERVE(c, S.sp_off, (size_t)Eall * 4 + 16);
+        const size_t ix_tmp = sp_sort_temp_bytes((size_t)Eall);
+        CCM_RESERVE(c, S.sp_tmp, ix_tmp + 256);
+        int* flags = S.info_dev.as<int>() + 8;
+        const int init_flags[2] = { 0, 0x7FFFFFFF };
+        CCM_HIP(c, hipMemcpyAsync(flags, init_flags, 8, hipMemcpyHostToDevice, st));
+        ba_launch_index_check(st, S.edge_pose.as<int>(), S.edge_point.as<int>(), Eall, P, Lall, flags, S.pt_first.as<int>());
+        ba_launch_index_pose_keys(st, S.edge_pose.as<int>(), S.free_of.as<int>(), Eall, P, nfree, S.sp_key.as<unsigned>(), S.sp_off.as<unsigned>());
+        CCM_HIP(c, sp_sort_u32(st, S.sp_tmp.p, ix_tmp, S.sp_key.as<unsigned>(), S.sp_key2.as<unsigned>(), S.sp_off.as<unsigned>(),
+                               S.pose_edges.as<unsigned>(), (size_t)Eall));
+        ba_launch_index_pose_first(st, S.sp_key2.as<unsigned>(), Eall, nfree, S.pose_first.as<int>());
+        int got[2] = { 0, 0 };
+        CCM_HIP(c, hipMemcpyAsync(got, flags, 8, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        if (got[1] != 0x7FFFFFFF) return ccm_fail(c, CCM_E_ARG, "edge %d references a vertex out of range", got[1]);
+        dev_indexed = got[0] == 0;
+    }
     std::vector<int> perm;
     bool sorted = true;
-    int n_local = 0;
-    {
+    int n_local = dev_indexed ? Eall : 0;
+    if (!dev_indexed) {
         std::vector<int> cnt(NT, 0), bad(NT, 0), first_l(NT, -1), first_p(NT, -1), last_l(NT, -1), last_p(NT, -1);
         std::vector<long long> out_of_range(NT, -1);
         pfor([&](int t) {
@@ -312,7 +343,7 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     std::vector<int> pose_first(nfree + 1, 0);
     std::unique_ptr<int[]> pose_edges;                        // every slot is written below: no zero-fill of 7 MB
     size_t n_pose_edges = 0;
-    {
+    if (!dev_indexed) {
         std::vector<std::vector<int>> hist(NT, std::vector<int>(nfree + 1, 0));
         pfor([&](int t) {
             const auto r = slice(E, t);
@@ -344,19 +375,20 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
 
     lap("host: sort + index edges");
     // ---- device buffers
-    int rc;
     if ((rc = upload(c, S.poses, pb->poses, 7 * (size_t)P))) return rc;
     if ((rc = upload(c, S.intr, pb->intr, 4 * (size_t)P))) return rc;
-    if ((rc = upload(c, S.free_of, free_of.data(), P))) return rc;
     if ((rc = upload(c, S.pose_of_free, pose_of_free.data(), nfree))) return rc;
     if ((rc = upload(c, S.points, pb->points + 3 * (size_t)l0, 3 * (size_t)L))) return rc;
-    if ((rc = upload(c, S.edge_pose, e_pose, E))) return rc;
-    if ((rc = upload(c, S.edge_point, e_pt, E))) return rc;
     if ((rc = upload(c, S.obs, e_obs, 2 * (size_t)E))) return rc;
     if ((rc = upload(c, S.info, e_info, E))) return rc;
-    if ((rc = upload(c, S.pt_first, pt_first.data(), L + 1))) return rc;
-    if ((rc = upload(c, S.pose_first, pose_first.data(), nfree + 1))) return rc;
-    if ((rc = upload(c, S.pose_edges, pose_edges.get(), n_pose_edges))) return rc;
+    if (!dev_indexed) {                                        // (the device path has these already)
+        if ((rc = upload(c, S.free_of, free_of.data(), P))) return rc;
+        if ((rc = upload(c, S.edge_pose, e_pose, E))) return rc;
+        if ((rc = upload(c, S.edge_point, e_pt, E))) return rc;
+        if ((rc = upload(c, S.pt_first, pt_first.data(), L + 1))) return rc;
+        if ((rc = upload(c, S.pose_first, pose_first.data(), nfree + 1))) return rc;
+        if ((rc = upload(c, S.pose_edges, pose_edges.get(), n_pose_edges))) return rc;
+    }
     const size_t nxl = (size_t)n + 3 * (size_t)L;
     CCM_RESERVE(c, S.Rt, 12 * (size_t)P * 8);
     CCM_RESERVE(c, S.active, std::max<size_t>(E, 16)); CCM_RESERVE(c, S.flags, std::max<size_t>(E, 16));

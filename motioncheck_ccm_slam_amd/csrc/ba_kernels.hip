@@ -323,6 +323,61 @@ void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
     if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_ba_lin_pose<4>, dim3(D.nfree), dim3(256), 0, s, D, hd);
     else if (D.nfree > 0) hipLaunchKernelGGL(k_ba_lin_pose_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, hd);
 }
+// ---- the edge list's index structures made on the device (large unsharded maps: the host passes over 1.8 M edges were 2 ms of a 39 ms call)
+// flags[0] |= 1 when the list is not sorted by (landmark, keyframe); flags[1] = lowest edge with a vertex index out of range (or INT_MAX)
+__global__ __launch_bounds__(256) void k_ix_check(const int* __restrict__ edge_pose, const int* __restrict__ edge_point, int E, int P, int L, int* __restrict__ flags)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int l = edge_point[e], p = edge_pose[e];
+    if (p < 0 || p >= P || l < 0 || l >= L) { atomicMin(flags + 1, e); return; }
+    if (e > 0) {
+        const int lp = edge_point[e - 1], pp = edge_pose[e - 1];
+        if (l < lp || (l == lp && p < pp)) atomicOr(flags, 1);
+    }
+}
+// pt_first[q] = first edge of landmark q (edges sorted by landmark): where the landmark index changes; landmarks without edges start
+// where the next one does
+__global__ __launch_bounds__(256) void k_ix_pt_first(const int* __restrict__ edge_point, int E, int L, int* __restrict__ pt_first)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e > E) return;
+    const int l = e < E ? min(max(edge_point[e], 0), L - 1) : L;          // (clamped: an out-of-range list is rejected by the caller anyway)
+    const int lp = e > 0 ? min(max(edge_point[e - 1], 0), L - 1) : -1;
+    for (int q = lp + 1; q <= l; q++) pt_first[q] = e;
+}
+__global__ __launch_bounds__(256) void k_ix_pose_keys(const int* __restrict__ edge_pose, const int* __restrict__ free_of, int E, int P, int nfree,
+                                                      unsigned* __restrict__ key, unsigned* __restrict__ val)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int p = edge_pose[e];
+    const int f = (p >= 0 && p < P) ? free_of[p] : -1;
+    key[e] = f >= 0 ? (unsigned)f : (unsigned)nfree;                      // fixed keyframes' edges sort behind the free ones
+    val[e] = (unsigned)e;
+}
+// pose_first[f] = first position of key f in the sorted keys; pose_first[nfree] = number of edges of free keyframes
+__global__ __launch_bounds__(256) void k_ix_pose_first(const unsigned* __restrict__ skey, int E, int nfree, int* __restrict__ pose_first)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > E) return;
+    const int f = k < E ? (int)skey[k] : nfree + 1;
+    const int fp = k > 0 ? (int)skey[k - 1] : -1;
+    for (int q = fp + 1; q <= min(f, nfree); q++) pose_first[q] = k;
+}
+void ba_launch_index_check(hipStream_t s, const int* edge_pose, const int* edge_point, int E, int P, int L, int* flags, int* pt_first)
+{
+    hipLaunchKernelGGL(k_ix_check, dim3(nblk(E, 256)), dim3(256), 0, s, edge_pose, edge_point, E, P, L, flags);
+    hipLaunchKernelGGL(k_ix_pt_first, dim3(nblk((long long)E + 1, 256)), dim3(256), 0, s, edge_point, E, L, pt_first);
+}
+void ba_launch_index_pose_keys(hipStream_t s, const int* edge_pose, const int* free_of, int E, int P, int nfree, unsigned* key, unsigned* val)
+{
+    hipLaunchKernelGGL(k_ix_pose_keys, dim3(nblk(E, 256)), dim3(256), 0, s, edge_pose, free_of, E, P, nfree, key, val);
+}
+void ba_launch_index_pose_first(hipStream_t s, const unsigned* skey, int E, int nfree, int* pose_first)
+{
+    hipLaunchKernelGGL(k_ix_pose_first, dim3(nblk((long long)E + 1, 256)), dim3(256), 0, s, skey, E, nfree, pose_first);
+}
 void ba_launch_backsub(hipStream_t s, const BaDev& D)
 {
     if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub<BA_LM_LANES>, dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D);

@@ -59,6 +59,28 @@ def test_edge_order_does_not_matter(ctx):
     assert r2["iterations_done"] == r["iterations_done"] and r2["chi2_final"] == r["chi2_final"]
 
 
+def test_large_edge_list_indexed_on_the_device(ctx):
+    """Above 400,000 edges an unsharded map's edge list is checked and indexed on the device (k_ix_*).  The device path (sorted list),
+    the host path forced by CCM_BA_HOST_INDEX=1 (child process) and the fallback for a shuffled list must give bit-identical results."""
+    import subprocess, sys
+    g = synth.gba_graph(n_kf=600, n_points=60000, n_agents=3, seed=11)
+    assert len(g["edge_pose"]) >= 400000
+    r = Optimizer.MapFusionGBA(g, 3, ctx=ctx)
+    rng = np.random.default_rng(4)
+    o = rng.permutation(len(g["edge_pose"]))
+    g2 = dict(g, edge_pose=g["edge_pose"][o], edge_point=g["edge_point"][o], obs=g["obs"][o], info=g["info"][o])
+    r2 = Optimizer.MapFusionGBA(g2, 3, ctx=ctx)
+    assert (r2["poses"] == r["poses"]).all() and (r2["points"] == r["points"]).all() and r2["chi2_final"] == r["chi2_final"]
+    code = ("import numpy as np\nfrom motioncheck_ccm_slam_amd import _lib, synth\nfrom motioncheck_ccm_slam_amd.optimizer import Optimizer\n"
+            "g = synth.gba_graph(n_kf=600, n_points=60000, n_agents=3, seed=11)\nr = Optimizer.MapFusionGBA(g, 3, ctx=_lib.Context(0))\n"
+            "print(repr(float(r['chi2_final'])), repr(float(np.abs(r['poses']).sum())))")
+    env = dict(os.environ, CCM_BA_HOST_INDEX="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    chi, ps = out.stdout.strip().splitlines()[-1].split()
+    assert float(chi) == float(r["chi2_final"]) and float(ps) == float(np.abs(r["poses"]).sum())
+
+
 def test_noise_free_graph_is_recovered(ctx):
     g = synth.local_ba_graph(n_free=8, n_fixed=3, n_points=600, seed=31, noise=False)
     r = Optimizer.BundleAdjustmentClient(g, 25, bRobust=False, ctx=ctx)

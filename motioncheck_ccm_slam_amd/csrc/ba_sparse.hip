@@ -650,9 +650,6 @@ void pcg_launch_coarse_invert(hipStream_t s, double* A, int ncp, double* D, int*
     }
 }
 
-// yc = Ac^-1 (R r), z += R^T yc: rcl holds the per-cluster sums of the residual (written by k_pcg_init / k_pcg_update), a
-// wave per coarse row (aggregate I, component d) which then adds its value to component d of the aggregate's keyframes;
-// cpart[workgroup] = the workgroup's share of (R r) . yc, which is the coarse level's contribution to r.z
 // P^T r comes from the kernels that make r (k_pcg_init, k_pcg_update): a block of PCG_UPD_TPB scalars is PCG_UPD_KF consecutive
 // keyframes, which touch at most PCG_RSLOTS consecutive aggregates (the first is pcg_hat(first keyframe).i0); thread (slot, d) walks
 // the block's keyframes in order and leaves its partial sum in rpart[block][slot][d].  k_pcg_coarse adds the two or three blocks
@@ -1053,7 +1050,7 @@ int pcg_coarse_agg_keyframes(int nfree) { return PCG_CL * pcg_agg_clusters(nfree
 int pcg_coarse_dim(int nfree) { return PCG_CDOF * pcg_coarse_aggregates(nfree); }
 int pcg_coarse_pitch(int nfree) { return nblk(pcg_coarse_dim(nfree), INV_B) * INV_B; }
 int pcg_coarse_parts(int nfree) { return nblk(pcg_coarse_dim(nfree), 4); }
-// Ac = R H R^T as a full (padded) matrix in `Ac`
+// Ac = P^T H P as a full (padded) matrix in `Ac`
 void pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, const double* svec, const double* cen, double* Ac)
 {
     const int nagg = pcg_coarse_aggregates(nfree), nc = PCG_CDOF * nagg, ncp = pcg_coarse_pitch(nfree);

@@ -384,12 +384,12 @@ def main():
                       "ms_per_call": round(float(np.median(tl)) * 1e3, 3), "iterations": rl["iterations_done"], "outliers": int(rl["outlier"].sum())}
                 if not args.no_cpu:
                     from oracle import oracle_py as O
-                    t1 = time.perf_counter(); O.ba_solve(gl, 5, float(np.sqrt(5.991)), 10); lb["cpu_oracle_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
+                    t1 = time.perf_counter(); O.ba_solve(gl, 5, float(np.float32(np.sqrt(5.991))), 10); lb["cpu_oracle_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
                 gba["local_ba"] = lb
             if solo and not args.no_cpu:
                 from oracle import oracle_py as O
                 tc = time.perf_counter()
-                rc = O.ba_solve(g, 2, float(np.sqrt(5.99)))
+                rc = O.ba_solve(g, 2, float(np.float32(np.sqrt(5.99))))
                 tc = time.perf_counter() - tc
                 gba["cpu_baseline"] = {"value": round(rc["iterations_done"] / tc, 4), "unit": "LM iterations/s", "cores": 1, "kind": "port",
                                        "sample": "config 5 itself (2000 KF / 200k points / %d edges), 2 LM iterations of the oracle incl. its one-off "

@@ -21,7 +21,11 @@
 extern "C" {
 #endif
 
-#define CCM_ABI_VERSION 1
+/* Bumped whenever a struct, an enum count or a prototype changes (3: ccm_ba_result.pcg_pipelined; round 2 had already changed
+ * ccm_essential_graph, CCM_PROF_COUNT and removed ccm_comm_init_shm under version 1).  A caller compiled against another version
+ * must not call further: ccm_abi_version() returns the library's value, compare it with this macro (the Python mirror and
+ * shim/ccm_shim.h do). */
+#define CCM_ABI_VERSION 3
 
 enum {
     CCM_OK = 0,
@@ -354,7 +358,8 @@ typedef struct {
     int32_t schur_blocks;     /* non-zero 6x6 blocks (upper triangle) */
     int64_t schur_pairs;      /* (landmark, pose-pair) contributions on this rank */
     int32_t pcg_iterations;   /* conjugate-gradient iterations, all trials (0 on the dense path) */
-    int32_t pcg_fallbacks;    /* trials that fell back to the dense solve */
+    int32_t pcg_fallbacks;    /* trials whose first solver gave up (pipelined -> classic PCG, PCG -> dense solve) */
+    int32_t pcg_pipelined;    /* 1 = the two-kernel pipelined PCG iteration ran (pcg_tol >= 1e-7), 0 = the classic one or the dense solve */
 } ccm_ba_result;
 
 int ccm_ba_solve(ccm_ctx*, ccm_ba_problem*, const ccm_ba_options*, ccm_ba_result*);

@@ -94,9 +94,10 @@ class BaResult(C.Structure):
                 ("t_linearize", C.c_double), ("t_schur", C.c_double), ("t_solve", C.c_double),
                 ("t_update", C.c_double), ("edge_outlier", C.c_void_p),
                 ("schur_blocks", C.c_int32), ("schur_pairs", C.c_int64), ("pcg_iterations", C.c_int32),
-                ("pcg_fallbacks", C.c_int32)]
+                ("pcg_fallbacks", C.c_int32), ("pcg_pipelined", C.c_int32)]
 
 
+ABI_VERSION = 3        # CCM_ABI_VERSION of the include/ccm_hot.h these ctypes structures were written against
 _lib = None
 
 
@@ -109,6 +110,10 @@ def load():
         raise ImportError("%s not found: build it with `make -C motioncheck_ccm_slam_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    # the structures below mirror include/ccm_hot.h at this version; a stale library would read and write past them
+    if lib.ccm_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this package mirrors version %d of include/ccm_hot.h: rebuild it"
+                          % (LIB_PATH, lib.ccm_abi_version(), ABI_VERSION))
     lib.ccm_create.restype = C.c_void_p
     lib.ccm_create.argtypes = [C.c_int, C.c_int]
     lib.ccm_destroy.argtypes = [C.c_void_p]

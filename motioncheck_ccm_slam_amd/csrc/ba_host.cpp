@@ -17,6 +17,8 @@
 #include <chrono>
 #include <memory>
 #include <numeric>
+#include <new>
+#include <system_error>
 #include <thread>
 
 int comm_ranks(const ccm_ctx* c);
@@ -58,9 +60,19 @@ void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree
 void pcg_launch_iter(hipStream_t, const double* Hb, const int* row_ptr, const unsigned* ekey, const unsigned* eval, const double* Minv,
                      int nfree, double* w, double* pap_part, double* part, double* sc, int parity, const PcgCoarse& C);
 void pcg_launch_publish(hipStream_t, int nfree, double* part, double* sc, const PcgCoarse& C);
+size_t ppcg_state_doubles(int nfree);
+size_t ppcg_ca_doubles(int nfree);
+bool ppcg_supported(int nfree);
+void ppcg_launch_expand(hipStream_t, const double* Hb, const unsigned* ekey, const unsigned* eval, int n_ent, int nfree, double* Hf, int* ecol);
+hipError_t ppcg_launch_init(hipStream_t, const double* b, const double* Minv, const int* row_ptr, int nfree, double* wb, double* part, double* sc,
+                            const PcgCoarse& C, const PpcgBufs& B);
+void ppcg_launch_iter(hipStream_t, const double* Minv, const int* row_ptr, int nfree, double* wb, double* part, double* sc, const PcgCoarse& C, const PpcgBufs& B);
+void ppcg_launch_publish(hipStream_t, const double* part, int nfree, double* sc);
 int pcg_coarse_dim(int nfree);
 int pcg_coarse_parts(int nfree);
-void pcg_launch_coarse_build(hipStream_t, const double* Hb, const uint8_t* map, const int* id, int nfree, const double* svec, const double* cen, double* Ac);
+void pcg_launch_coarse_mark(hipStream_t, const int* blk_row, const int* blk_col, int nb, int nfree, uint8_t* aggmap);
+hipError_t pcg_launch_coarse_build(hipStream_t, const double* Hb, const uint8_t* map, const int* id, int nfree, const double* svec, const double* cen,
+                                   const int* pairs, int npairs, double* Ac);
 int pcg_coarse_aggregates(int nfree);
 int pcg_coarse_agg_keyframes(int nfree);
 void pcg_launch_coarse_mirror(hipStream_t, double* A, int ncp);
@@ -82,18 +94,24 @@ void ba_launch_deactivate(hipStream_t, const BaDev&, const uint8_t* flag);
 struct BaState {
     hipStream_t side = nullptr;            // coarse-level inversion, concurrent with the PCG of the current trial
     hipEvent_t ev_hb = nullptr;            // the side stream has finished reading the reduced system
+    hipEvent_t ev_inv = nullptr;           // the side stream has finished an inversion
+    hipEvent_t ev_copy = nullptr;          // the main stream has copied the last inverse out of the side stream's work matrix
+    std::vector<hipEvent_t> clock_ev;      // phase timers of large problems (events instead of stream synchronisations)
     double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
     DevBuf poses, Rt, intr, free_of, pose_of_free, points, edge_pose, edge_point, obs, info, active, err,
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
            partial, scal, flags, info_dev, tmp_ll, pp_diag, gather,
            sp_cnt, sp_off, sp_key, sp_val, sp_key2, sp_val2, sp_map, sp_id, sp_tmp, blk_row, blk_col, diag_id, seg_start, seg_end,
-           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw, pcg_svec;
+           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw, pcg_svec, pcg_hf, pcg_ecol, pcg_ca, pcg_aggmap, pcg_pairs;
 };
 void ba_state_free(BaState* s)
 {
     if (!s) return;
     if (s->side) (void)hipStreamSynchronize(s->side);
     if (s->ev_hb) (void)hipEventDestroy(s->ev_hb);
+    if (s->ev_inv) (void)hipEventDestroy(s->ev_inv);
+    if (s->ev_copy) (void)hipEventDestroy(s->ev_copy);
+    for (hipEvent_t e : s->clock_ev) (void)hipEventDestroy(e);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->pinned) (void)hipHostFree(s->pinned);
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
@@ -102,7 +120,7 @@ void ba_state_free(BaState* s)
                       &s->partial, &s->scal, &s->flags, &s->info_dev, &s->tmp_ll, &s->pp_diag, &s->gather,
                       &s->sp_cnt, &s->sp_off, &s->sp_key, &s->sp_val, &s->sp_key2, &s->sp_val2, &s->sp_map, &s->sp_id, &s->sp_tmp, &s->blk_row,
                       &s->blk_col, &s->diag_id, &s->seg_start, &s->seg_end, &s->ent_key, &s->ent_val, &s->ent_key2, &s->ent_val2, &s->row_ptr,
-                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc, &s->pcg_aci, &s->pcg_coarse, &s->pcg_acw, &s->pcg_svec };
+                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc, &s->pcg_aci, &s->pcg_coarse, &s->pcg_acw, &s->pcg_svec, &s->pcg_hf, &s->pcg_ecol, &s->pcg_ca, &s->pcg_aggmap, &s->pcg_pairs };
     for (DevBuf* b : all) b->release();
     delete s;
 }
@@ -168,7 +186,18 @@ int ccm_ba_landmark_cuts(const int32_t* edge_point, int n_edges, int n_points, i
     return CCM_OK;
 }
 
+static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_ba_result* res);
+// No C++ exception may cross the C ABI (std::terminate would take the host process -- a SLAM server -- down): allocation failures of
+// the host-side index vectors and anything else thrown below come back as status codes.
 int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_ba_result* res)
+{
+    try { return ba_solve_impl(c, pb, opt, res); }
+    catch (const std::bad_alloc&) { return c ? ccm_fail(c, CCM_E_NOMEM, "ccm_ba_solve: host allocation failed") : CCM_E_NOMEM; }
+    catch (const std::exception& e) { return c ? ccm_fail(c, CCM_E_DEVICE, "ccm_ba_solve: %s", e.what()) : CCM_E_DEVICE; }
+    catch (...) { return c ? ccm_fail(c, CCM_E_DEVICE, "ccm_ba_solve: unknown exception") : CCM_E_DEVICE; }
+}
+
+static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_ba_result* res)
 {
     RoctxRange roctx_("ccm_ba_solve");
     if (!c || !pb || !opt) return CCM_E_ARG;
@@ -230,8 +259,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     auto pfor = [&](auto&& fn) {
         if (NT == 1) { fn(0); return; }
         std::vector<std::thread> th;
-        for (int t = 1; t < NT; t++) th.emplace_back([&fn, t]() { fn(t); });
+        int started = 1;                                   // slices 1 .. started-1 have a thread
+        try { for (int t = 1; t < NT; t++) { th.emplace_back([&fn, t]() { fn(t); }); started = t + 1; } }
+        catch (const std::system_error&) {}                // thread or process limit: the remaining slices run here, same results
         fn(0);
+        for (int t = started; t < NT; t++) fn(t);
         for (auto& x : th) x.join();
     };
     auto slice = [&](long long total, int t) { return std::pair<long long, long long>(total * t / NT, total * (t + 1) / NT); };
@@ -469,8 +501,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         CCM_HIP(c, hipMemsetAsync(S.row_ptr.p, 0, (size_t)nfree * 8, st));
         sp_launch_row_ptr(st, S.ent_key2.as<unsigned>(), 2 * nb, nfree, S.row_ptr.as<int>());
         CCM_RESERVE(c, S.Hb, (36 * (size_t)nb + (size_t)n + 8) * 8);          // blocks, then bschur: one all-reduce covers both
-        CCM_RESERVE(c, S.Minv, pcg_minv_bytes(nfree)); CCM_RESERVE(c, S.pcg_w, 6 * (size_t)n * 8 + 64);
-        CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)n / 192 + 4) * 3 * 8 + 64);
+        CCM_RESERVE(c, S.Minv, pcg_minv_bytes(nfree)); CCM_RESERVE(c, S.pcg_w, std::max(6 * (size_t)n, ppcg_state_doubles(nfree)) * 8 + 64);
+        CCM_RESERVE(c, S.pcg_pap, (size_t)nfree * 8 + 64); CCM_RESERVE(c, S.pcg_part, ((size_t)nfree + (size_t)n / 192 + 4) * 3 * 8 + 64);
         CCM_RESERVE(c, S.pcg_sc, 64 * 8);
         {
             const size_t nc = (size_t)pcg_coarse_dim(nfree), ncp = (size_t)pcg_coarse_pitch(nfree);
@@ -505,11 +537,17 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     // second preconditioner level (ba_sparse.hip): on for systems with at least 64 coarse unknowns
     static const bool want_coarse = !(getenv("CCM_PCG_COARSE") && atoi(getenv("CCM_PCG_COARSE")) == 0);
     PcgCoarse PC{};
+    std::vector<int> coarse_pairs;                         // (I, J), I <= J
     const int nc = nfree > 0 ? pcg_coarse_dim(nfree) : 0, ncp = nfree > 0 ? pcg_coarse_pitch(nfree) : 0;
     if (use_pcg && want_coarse && nc >= 64 && nc <= 2304) {      // beyond: the cubic inversion would outlast an LM trial (more than 24 576 free keyframes)
         if (!S.side) {
-            if (hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking) != hipSuccess) { S.side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed"); }
+            // lowest priority: the inversion has a whole LM trial to finish, the PCG kernels it shares the GPU with are the critical path
+            int prio_least = 0, prio_greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+            if (hipStreamCreateWithPriority(&S.side, hipStreamNonBlocking, prio_least) != hipSuccess) { S.side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed"); }
             CCM_HIP(c, hipEventCreateWithFlags(&S.ev_hb, hipEventDisableTiming));
+            CCM_HIP(c, hipEventCreateWithFlags(&S.ev_inv, hipEventDisableTiming));
+            CCM_HIP(c, hipEventCreateWithFlags(&S.ev_copy, hipEventDisableTiming));
         }
         PC.Aci = S.pcg_aci.as<double>();
         PC.rc = S.pcg_coarse.as<double>();
@@ -517,7 +555,33 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         PC.cpart = PC.yc + nc;
         PC.svec = S.pcg_svec.as<double>();
         PC.cen = PC.svec + 3 * (size_t)nfree;
+        // the aggregate pairs that hold a block (the grid of the coarse matrix's assembly): fixed for the call
+        const int nagg = pcg_coarse_aggregates(nfree);
+        CCM_RESERVE(c, S.pcg_aggmap, (size_t)nagg * nagg + 16);
+        CCM_HIP(c, hipMemsetAsync(S.pcg_aggmap.p, 0, (size_t)nagg * nagg, st));
+        pcg_launch_coarse_mark(st, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, nfree, S.pcg_aggmap.as<uint8_t>());
+        std::vector<uint8_t> am((size_t)nagg * nagg);
+        CCM_HIP(c, hipMemcpyAsync(am.data(), S.pcg_aggmap.p, am.size(), hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        for (int I = 0; I < nagg; I++)
+            for (int J = I; J < nagg; J++) if (am[(size_t)I * nagg + J]) { coarse_pairs.push_back(I); coarse_pairs.push_back(J); }
+        CCM_RESERVE(c, S.pcg_pairs, coarse_pairs.size() * 4 + 16);
+        CCM_HIP(c, hipMemcpyAsync(S.pcg_pairs.p, coarse_pairs.data(), coarse_pairs.size() * 4, hipMemcpyHostToDevice, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
     }
+    // Which iteration: the pipelined one (two kernels per iteration, ba_sparse.hip) for the tolerances a BA asks for; its recurrences
+    // stall near a relative residual of 1e-9, so a caller that wants more than 1e-7 gets the classic four-kernel iteration.
+    static const double env_tol = getenv("CCM_PCG_TOL") ? atof(getenv("CCM_PCG_TOL")) : 0.0;
+    const double pcg_tol = env_tol > 0 ? env_tol : (opt->pcg_tol > 0 ? opt->pcg_tol : 1e-6);   // relative residual (default: see ccm_hot.h)
+    static const int env_pipe = getenv("CCM_PCG_PIPELINED") ? atoi(getenv("CCM_PCG_PIPELINED")) : -1;            // test switch: 0 / 1 force
+    const bool pipelined = use_pcg && nfree > 0 && ppcg_supported(nfree) && (env_pipe >= 0 ? env_pipe != 0 : pcg_tol >= 1e-7);
+    PpcgBufs PB{};
+    if (pipelined) {
+        CCM_RESERVE(c, S.pcg_hf, 36 * 2 * (size_t)nb * 8 + 64); CCM_RESERVE(c, S.pcg_ecol, 2 * (size_t)nb * 4 + 64);
+        CCM_RESERVE(c, S.pcg_ca, ppcg_ca_doubles(nfree) * 8 + 64);
+        PB.Hf = S.pcg_hf.as<double>(); PB.ecol = S.pcg_ecol.as<int>(); PB.CA = S.pcg_ca.as<double>();
+    }
+    res->pcg_pipelined = pipelined ? 1 : 0;
     // The PCG inner loop is three or four small dependent kernels per iteration and is launch-bound when issued one by
     // one: capture a chunk of iterations (+ the scalar publication) into a HIP graph and replay it.
     // Chunk lengths (even: the r.z slot parity is the same at the start of every chunk): graphs of 8 and of 2 iterations; a host
@@ -535,9 +599,11 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         for (int gi = 0; gi < (PC.Aci ? 4 : 2); gi++) {
             const PcgCoarse& pc = (gi >> 1) ? PC : PC0;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                for (int k = 0; k < pcg_len[gi & 1]; k++)
-                    pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                    nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pc);
+                for (int k = 0; k < pcg_len[gi & 1]; k++) {
+                    if (pipelined) ppcg_launch_iter(st, S.Minv.as<double>(), S.row_ptr.as<int>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pc, PB);
+                    else pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                                         nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pc);
+                }
                 hipError_t e1 = hipStreamEndCapture(st, &pcg_graph[gi]);
                 hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec[gi], pcg_graph[gi], nullptr, nullptr, 0) : e1;
                 if (e2 != hipSuccess) {
@@ -549,9 +615,24 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
             if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG graph %d %s\n", gi, pcg_exec[gi] ? "ready" : "not used");
         }
     }
+    // The coarse inversion is 75 small launches (0.2 ms of host time per LM trial, during which the host does not answer the PCG's round
+    // trips): captured once, replayed with one call.
+    hipGraph_t inv_graph = nullptr; hipGraphExec_t inv_exec = nullptr;
+    struct InvGraphGuard { hipGraph_t& g; hipGraphExec_t& e; ~InvGraphGuard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } inv_guard{inv_graph, inv_exec};
+    if (PC.Aci && use_pcg) {
+        double* Aw = S.pcg_acw.as<double>();
+        if (hipStreamBeginCapture(S.side, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            pcg_launch_coarse_invert(S.side, Aw, ncp, Aw + (size_t)ncp * ncp, info_dev + 4);
+            pcg_launch_coarse_mirror(S.side, Aw, ncp);
+            hipError_t e1 = hipStreamEndCapture(S.side, &inv_graph);
+            hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&inv_exec, inv_graph, nullptr, nullptr, 0) : e1;
+            if (e2 != hipSuccess) { inv_exec = nullptr; (void)hipGetLastError(); }
+        } else (void)hipGetLastError();
+    }
     lap("PCG graph capture");
     bool hb_in_use = false;                                // the side stream is still reading this trial's reduced system
     bool coarse_ready = false, coarse_pending = false;     // an inverse is in Aci / an inversion is running on the side stream
+    bool copy_recorded = false;                            // ev_copy has been recorded in this call
 
     // *pbStopFlag (sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149).  With several ranks the decision must be
     // the same everywhere or a rank would leave the loop while the others wait in the next all-reduce: every rank's sample of
@@ -592,8 +673,19 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
         return CCM_OK;
     };
 
+    // Phase timers (t_linearize / t_schur / t_solve / t_update).  Small problems: host clock, booked where the next necessary
+    // synchronisation falls.  Large ones (fine_timers): an event on the stream at every phase boundary, read once at the end of the
+    // call -- round 2 synchronised the stream there instead, four idle gaps of 20-30 us per LM trial once a trial took 3 ms.
+    std::vector<int> clock_phase;                          // phase the interval ENDING at event i belongs to (-1: none)
+    auto tick = [&](int phase) {
+        if (!fine_timers) return;
+        const size_t i = clock_phase.size();
+        if (i == S.clock_ev.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return; S.clock_ev.push_back(e); }
+        if (hipEventRecord(S.clock_ev[i], st) == hipSuccess) clock_phase.push_back(phase);
+    };
     double huber = opt->huber_delta > 0 ? opt->huber_delta : 0.0;
     bool first_eval = true;
+    tick(-1);
     for (int stage = 0; stage < 2 && !res->stopped; stage++) {
         const int iterations = stage == 0 ? opt->iterations : opt->iterations2;
         if (iterations <= 0) { if (stage == 0) continue; else break; }
@@ -628,9 +720,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                 for (double v : dg) md = std::max(md, std::fabs(v));
                 lambda = 1e-5 * md; ni = 2; nBad = 0;
             }
-            if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
+            tick(0);
             lin_.end();
-            res->t_linearize += secs(t0, clk::now());
+            if (!fine_timers) res->t_linearize += secs(t0, clk::now());
             double rho = 0;
             int qmax = 0;
             do {
@@ -654,9 +746,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     { ProfScope ps(c, CCM_PROF_BA_BSCHUR); sp_launch_bschur(st, D, S.db.as<double>(), D.bs); }
                     if ((rc = comm_allreduce_f64(c, Hb, 36 * (size_t)nb + (size_t)n, false))) return rc;
                     sp_launch_add_lambda(st, S.diag_id.as<int>(), nfree, lambda, Hb);
-                    if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
+                    tick(1);
                     t2 = clk::now();
-                    res->t_schur += secs(t1, t2);
+                    if (!fine_timers) res->t_schur += secs(t1, t2);
                     bool solved = false;
                     if (use_pcg) {
                         int* bad = info_dev + 1;
@@ -666,13 +758,16 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         // the side stream while that trial's PCG ran (a preconditioner may be stale: lambda differs by the LM
                         // factor, H by one relinearisation); this trial's system starts the next inversion.  Which inverse a
                         // trial uses depends only on the trial number, never on timing, so all ranks do the same.
+                        volatile int* cinfo = reinterpret_cast<volatile int*>(S.pinned + 15);
+                        bool coarse_unverified = false;
                         if (PC.Aci && coarse_pending) {
-                            CCM_HIP(c, hipStreamSynchronize(S.side));                    // the inversion has normally been over for milliseconds
+                            // No host round trip: the main stream waits for the inversion (normally over for milliseconds), copies the
+                            // inverse, and the verdict of the inversion is read together with the first scalars of this trial's PCG.
+                            CCM_HIP(c, hipStreamWaitEvent(st, S.ev_inv, 0));
                             CCM_HIP(c, hipMemcpyAsync(PC.Aci, S.pcg_acw.p, (size_t)ncp * ncp * 8, hipMemcpyDeviceToDevice, st));
-                            int cinfo = 0;
-                            CCM_HIP(c, hipMemcpyAsync(&cinfo, info_dev + 4, 4, hipMemcpyDeviceToHost, st));
-                            CCM_HIP(c, hipStreamSynchronize(st));
-                            coarse_pending = false; coarse_ready = cinfo == 0;     // a system that was not positive definite leaves no usable inverse
+                            CCM_HIP(c, hipMemcpyAsync(S.pinned + 15, info_dev + 4, 4, hipMemcpyDeviceToHost, st));
+                            CCM_HIP(c, hipEventRecord(S.ev_copy, st));                   // the next inversion overwrites the work matrix: it waits for this copy
+                            coarse_pending = false; coarse_ready = true; coarse_unverified = true; copy_recorded = true;
                         }
                         const bool more_trials_planned = it + 1 < iterations || (stage == 0 && opt->iterations2 > 0);
                         // The next inversion (assembly of Ac from this trial's system, block Gauss-Jordan: 68 small launches, 0.2 ms
@@ -681,56 +776,87 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         bool side_todo = PC.Aci && more_trials_planned;
                         auto start_inversion = [&]() -> int {
                             double* Aw = S.pcg_acw.as<double>();
+                            if (copy_recorded) CCM_HIP(c, hipStreamWaitEvent(S.side, S.ev_copy, 0));
                             CCM_HIP(c, hipMemsetAsync(info_dev + 4, 0, 4, S.side));
-                            pcg_launch_coarse_build(S.side, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, PC.svec, PC.cen, Aw);
+                            CCM_HIP(c, pcg_launch_coarse_build(S.side, Hb, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), nfree, PC.svec, PC.cen, S.pcg_pairs.as<int>(),
+                                                               (int)(coarse_pairs.size() / 2), Aw));
                             CCM_HIP(c, hipEventRecord(S.ev_hb, S.side));                 // awaited before the next trial overwrites Hb
                             hb_in_use = true;
-                            pcg_launch_coarse_invert(S.side, Aw, ncp, Aw + (size_t)ncp * ncp, info_dev + 4);
-                            pcg_launch_coarse_mirror(S.side, Aw, ncp);
+                            if (inv_exec) CCM_HIP(c, hipGraphLaunch(inv_exec, S.side));
+                            else {
+                                pcg_launch_coarse_invert(S.side, Aw, ncp, Aw + (size_t)ncp * ncp, info_dev + 4);
+                                pcg_launch_coarse_mirror(S.side, Aw, ncp);
+                            }
+                            CCM_HIP(c, hipEventRecord(S.ev_inv, S.side));
                             CCM_HIP(c, hipGetLastError());
                             coarse_pending = true; side_todo = false;
                             return CCM_OK;
                         };
-                        const PcgCoarse& pcu = coarse_ready ? PC : PC0;
-                        const int glv = coarse_ready ? 2 : 0;
-                        pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
                         const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
-                        static const double env_tol = getenv("CCM_PCG_TOL") ? atof(getenv("CCM_PCG_TOL")) : 0.0;
-                        const double pcg_tol = env_tol > 0 ? env_tol : (opt->pcg_tol > 0 ? opt->pcg_tol : 1e-6);   // relative residual (default: see ccm_hot.h)
                         const double tol2 = pcg_tol * pcg_tol;
                         volatile double* sc = S.pinned;
-                        int itc = 0, badh = 0, last_len = 0;
-                        double rr_prev = 0;
-                        CCM_HIP(c, hipMemcpyAsync(&badh, bad, 4, hipMemcpyDeviceToHost, st));
-                        for (;;) {
-                            CCM_HIP(c, hipMemcpyAsync(S.pinned, S.pcg_sc.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
-                            CCM_HIP(c, hipStreamSynchronize(st));
-                            if (badh || !(sc[3] > 0.0) || !std::isfinite(sc[2])) { ok2 = 0; solved = true; break; }   // not positive definite
-                            if (sc[2] <= tol2 * sc[1]) { solved = true; break; }
-                            if (itc >= max_it) break;
-                            // iterations still needed if |r|^2 keeps contracting as over the last round trip; without an estimate
-                            // (first round trip, stagnation): 16, or 32 while there is no coarse level
-                            const double rr = sc[2], target = tol2 * sc[1];
-                            int need = coarse_ready ? 16 : 32;
-                            if (last_len > 0 && rr_prev > 0 && rr < rr_prev) {
-                                const double est = std::log(rr / target) / (std::log(rr_prev / rr) / last_len);
-                                need = (int)std::min(16.0, std::max(2.0, std::ceil(est)));       // (CG speeds up as it goes: a longer forecast overshoots)
-                            }
-                            const int n8 = need / pcg_len[0], n2 = (need - n8 * pcg_len[0] + pcg_len[1] - 1) / pcg_len[1];
-                            rr_prev = rr; last_len = n8 * pcg_len[0] + n2 * pcg_len[1];
-                            for (int which = 0; which < 2; which++) {
-                                hipGraphExec_t gexec = pcg_exec[glv + which];
-                                for (int rpt = 0; rpt < (which ? n2 : n8); rpt++) {
-                                    if (gexec) CCM_HIP(c, hipGraphLaunch(gexec, st));
-                                    else
-                                        for (int k = 0; k < pcg_len[which]; k++)
-                                            pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
-                                                            nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pcu);
+                        int itc = 0;
+                        volatile int& badh = *reinterpret_cast<volatile int*>(S.pinned + 11);   // page-locked: a copy to the stack would stall the host until it is done
+                        badh = 0;
+                        CCM_HIP(c, hipMemcpyAsync(S.pinned + 11, bad, 4, hipMemcpyDeviceToHost, st));
+                        if (pipelined) ppcg_launch_expand(st, Hb, S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), 2 * nb, nfree, PB.Hf, PB.ecol);
+                        // one run of the iteration: 0 = converged, 1 = not positive definite (or, pipelined, the recurrences broke down), 2 = no convergence
+                        // (3 = the coarse inverse this trial was to use came from a system that was not positive definite: run again without it)
+                        auto pcg_run = [&](bool pip) -> int {
+                            const PcgCoarse& pcu = coarse_ready ? PC : PC0;
+                            const int glv = coarse_ready ? 2 : 0;
+                            if (pip) CCM_HIP(c, ppcg_launch_init(st, D.bs, S.Minv.as<double>(), S.row_ptr.as<int>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(),
+                                                                 S.pcg_sc.as<double>(), pcu, PB));
+                            else pcg_launch_init(st, D.bs, S.Minv.as<double>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
+                            int last_len = 0;
+                            double rr_prev = 0;
+                            for (;;) {
+                                CCM_HIP(c, hipMemcpyAsync(S.pinned, S.pcg_sc.p, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+                                CCM_HIP(c, hipStreamSynchronize(st));
+                                if (coarse_unverified) { coarse_unverified = false; if (*cinfo != 0) return 3; }
+                                if (badh || !(sc[3] > 0.0) || !std::isfinite(sc[2])) return 1;
+                                if (sc[2] <= tol2 * sc[1]) return 0;
+                                if (itc >= max_it) return 2;
+                                // iterations still needed if |r|^2 keeps contracting as over the last round trip; without an estimate
+                                // (first round trip, stagnation): 16, or 32 while there is no coarse level
+                                const double rr = sc[2], target = tol2 * sc[1];
+                                int need = coarse_ready ? 16 : 32;
+                                if (last_len > 0 && rr_prev > 0 && rr < rr_prev) {
+                                    const double est = std::log(rr / target) / (std::log(rr_prev / rr) / last_len);
+                                    need = (int)std::min(16.0, std::max(2.0, std::ceil(est)));       // (CG speeds up as it goes: a longer forecast overshoots)
                                 }
+                                const int n8 = need / pcg_len[0], n2 = (need - n8 * pcg_len[0] + pcg_len[1] - 1) / pcg_len[1];
+                                rr_prev = rr; last_len = n8 * pcg_len[0] + n2 * pcg_len[1];
+                                for (int which = 0; which < 2; which++) {
+                                    hipGraphExec_t gexec = pip == pipelined ? pcg_exec[glv + which] : nullptr;     // the graphs hold the iteration chosen for this call
+                                    for (int rpt = 0; rpt < (which ? n2 : n8); rpt++) {
+                                        if (gexec) CCM_HIP(c, hipGraphLaunch(gexec, st));
+                                        else
+                                            for (int k = 0; k < pcg_len[which]; k++) {
+                                                if (pip) ppcg_launch_iter(st, S.Minv.as<double>(), S.row_ptr.as<int>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu, PB);
+                                                else pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                                                                     nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pcu);
+                                            }
+                                    }
+                                }
+                                // |r|^2 of the iterate the chunk ended on (the classic kernels publish it with every direction, one update late:
+                                // k_pcg_scalars brings sc[2], sc[3] up to date as well)
+                                if (pip) ppcg_launch_publish(st, S.pcg_part.as<double>(), nfree, S.pcg_sc.as<double>());
+                                else pcg_launch_publish(st, nfree, S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pcu);
+                                itc += last_len;
+                                if (side_todo && (rc = start_inversion())) return -rc;
                             }
-                            itc += last_len;
-                            if (side_todo && (rc = start_inversion())) return rc;
+                        };
+                        int status = pcg_run(pipelined);
+                        if (status == 3) { coarse_ready = false; status = pcg_run(pipelined); }
+                        if (status < 0) return -status;
+                        if (status == 1 && pipelined && !badh) {                 // a breakdown of the recurrences is not a verdict on the matrix: ask the classic iteration
+                            res->pcg_fallbacks++;
+                            status = pcg_run(false);
+                            if (status < 0) return -status;
                         }
+                        if (status == 1) { ok2 = 0; solved = true; }             // not positive definite
+                        else if (status == 0) solved = true;
                         if (side_todo && (rc = start_inversion())) return rc;
                         res->pcg_iterations += itc;
                         if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms, rel.res %.2e\n", itc, secs(t2, clk::now()) * 1e3, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)));
@@ -757,13 +883,13 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                         if (ranks == 1 && !fine_timers) dense_info_pending = true;
                         else { CCM_HIP(c, hipStreamSynchronize(st)); ok2 = *dense_info == 0; }
                     }
-                    if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
                 } else {
                     // no free keyframe: only the landmark inverse is needed for the back-substitution
                     sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>());
                     CCM_HIP(c, hipStreamSynchronize(st));
+                    tick(1);
                     t2 = clk::now();
-                    res->t_schur += secs(t1, t2);
+                    if (!fine_timers) res->t_schur += secs(t1, t2);
                 }
                 if (hb_in_use) { CCM_HIP(c, hipEventSynchronize(S.ev_hb)); hb_in_use = false; }     // long over: the assembly is the side stream's first 0.2 ms
                 if (ranks > 1 && nfree > 0) {
@@ -780,8 +906,9 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     CCM_HIP(c, hipStreamSynchronize(st));
                     ok2 = S.pinned[12] != 0.0;
                 }
+                tick(2);
                 auto t3 = clk::now();
-                res->t_solve += secs(t2, t3);
+                if (!fine_timers) res->t_solve += secs(t2, t3);
                 res->trials++;
                 double tempChi = DBL_MAX, scale = 0;
                 if (ok2) {
@@ -803,8 +930,8 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
                     if (L) CCM_HIP(c, hipMemcpyAsync(D.points, S.save_points.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
                 }
                 qmax++;
-                if (fine_timers) CCM_HIP(c, hipStreamSynchronize(st));
-                res->t_update += secs(t3, clk::now());
+                tick(3);
+                if (!fine_timers) res->t_update += secs(t3, clk::now());
             } while (rho < 0 && qmax < 10 && !stop_requested());
             res->iterations_done++;
             res->chi2_final = currentChi; res->lambda_final = lambda;
@@ -815,6 +942,14 @@ int ccm_ba_solve(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* opt, ccm_
     }
 
     if (S.side) CCM_HIP(c, hipStreamSynchronize(S.side));
+    if (fine_timers && clock_phase.size() > 1) {
+        CCM_HIP(c, hipStreamSynchronize(st));
+        double* tp[4] = { &res->t_linearize, &res->t_schur, &res->t_solve, &res->t_update };
+        for (size_t i = 1; i < clock_phase.size(); i++) {
+            float ms = 0.f;
+            if (clock_phase[i] >= 0 && hipEventElapsedTime(&ms, S.clock_ev[i - 1], S.clock_ev[i]) == hipSuccess) *tp[clock_phase[i]] += 1e-3 * (double)ms;
+        }
+    }
     lap("LM loop");
     // ---- results
     CCM_HIP(c, hipMemcpyAsync(pb->poses, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToHost, st));

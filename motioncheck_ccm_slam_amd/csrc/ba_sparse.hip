@@ -15,6 +15,7 @@
 // systems and non-converging ones are scattered into a dense array and go to the dense solve at the end of this file.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdlib>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
 #include <cstdint>
@@ -146,11 +147,17 @@ __global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double lambda, doubl
     if (e >= D.E) return;
     const double* H = D.Hll + 9 * (long long)D.edge_point[e];
     // lower Cholesky factor of H + lambda I (upper half of H read)
+    // Pivots: in exact arithmetic each is >= lambda > 0 (H is a sum of J^T J terms).  For a landmark block that is rank-deficient
+    // (one observation, or no parallax) and a late, tiny lambda the computed second or third pivot can round to <= 0, and its square
+    // root would poison every reduced block the landmark touches.  A pivot below the rounding level of its own diagonal entry is
+    // noise either way, so it is held at that level (2^-52 of the entry): the step stays finite like the reference's, whose 3 x 3
+    // inverse (Eigen's cofactor formula, = inv3 above, used for the back-substitution) does not take square roots.
+    const double d1 = H[4] + lambda, d2 = H[8] + lambda;
     const double l00 = sqrt(H[0] + lambda), i00 = 1.0 / l00;
     const double l10 = H[1] * i00, l20 = H[2] * i00;
-    const double l11 = sqrt((H[4] + lambda) - l10 * l10), i11 = 1.0 / l11;
+    const double l11 = sqrt(fmax(d1 - l10 * l10, 0x1p-52 * d1)), i11 = 1.0 / l11;
     const double l21 = (H[5] - l20 * l10) * i11;
-    const double i22 = 1.0 / sqrt((H[8] + lambda) - l20 * l20 - l21 * l21);
+    const double i22 = 1.0 / sqrt(fmax(d2 - l20 * l20 - l21 * l21, 0x1p-52 * d2));
     const double* B = D.Hpl + 18 * (long long)e;
     double* y = Y + 18 * (long long)e;
 #pragma unroll
@@ -339,34 +346,58 @@ __global__ __launch_bounds__(256) void k_pcg_cl_gather(const double* __restrict_
     M[cc * PCG_CN + rr] = v;
 }
 // in-place inverse of every cluster matrix by Gauss-Jordan without pivoting (SPD); unused rows of the last cluster
-// are made identity; a non-positive pivot raises `bad`.  The matrix is overwritten column by column with its inverse
-// (the same arithmetic as eliminating [A | I], without storing the half that is known to be 0 / 1).
+// are made identity; a non-positive pivot raises `bad`.  The matrix lives in REGISTERS: thread (ty, tx) of the 16 x 16 workgroup owns
+// the 3 x 3 elements (ty + 16 a, tx + 16 b); per pivot p the owners of column p and of row p publish them in LDS (two alternating
+// buffers: one barrier per pivot) and every thread reads the three column and three row values its elements need -- the scheme of
+// k_inv_diag below.  (Round 2 held the matrix in LDS with two barriers per pivot: 71 us per LM trial, on the critical path.)
+static_assert(PCG_CN == 48, "k_pcg_cl_invert tiles a 48 x 48 cluster as 16 x 16 threads x 3 x 3 elements");
 __global__ __launch_bounds__(256) void k_pcg_cl_invert(double* __restrict__ Mc, int nfree, int* __restrict__ bad)
 {
-    __shared__ double a[PCG_CN][PCG_CN + 1];                 // + 1: odd row stride (bank conflicts on column reads)
-    __shared__ double fcol[PCG_CN], prow[PCG_CN];
+    __shared__ double fcol[2][PCG_CN], prow[2][PCG_CN];
+    __shared__ int s_bad;
     double* M = Mc + (long long)blockIdx.x * PCG_CN * PCG_CN;
     const int used = 6 * min(PCG_CL, nfree - (int)blockIdx.x * PCG_CL);
-    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 256) {
-        const int r = i / PCG_CN, c = i - r * PCG_CN;
-        a[r][c] = (r < used && c < used) ? M[i] : (r == c ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    bool ok = true;
-    for (int k = 0; k < PCG_CN; k++) {
-        const double piv = a[k][k];
-        if (!(piv > 0.0)) ok = false;
-        const double ip = 1.0 / piv;
-        if (threadIdx.x < PCG_CN) { fcol[threadIdx.x] = a[threadIdx.x][k]; prow[threadIdx.x] = ((int)threadIdx.x == k ? 1.0 : a[k][threadIdx.x]) * ip; }
-        __syncthreads();                                         // everyone has read the pivot, the pivot row and the pivot column
-        for (int e = threadIdx.x; e < PCG_CN * PCG_CN; e += 256) {
-            const int i = e / PCG_CN, j = e - i * PCG_CN;
-            a[i][j] = i == k ? prow[j] : ((j == k ? 0.0 : a[i][j]) - fcol[i] * prow[j]);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double a[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int r = ty + 16 * i, c = tx + 16 * j; a[i][j] = (r < used && c < used) ? M[r * PCG_CN + c] : (r == c ? 1.0 : 0.0); }
+    if (threadIdx.x == 0) s_bad = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (tx + 16 * j == 0) fcol[0][ty + 16 * i] = a[i][j];
+            if (ty + 16 * i == 0) prow[0][tx + 16 * j] = a[i][j];
         }
+    __syncthreads();
+    for (int p = 0; p < PCG_CN; p++) {
+        const int cur = p & 1, nxt = cur ^ 1;
+        const double piv = prow[cur][p];
+        if (!(piv > 0.0) && threadIdx.x == 0) s_bad = 1;
+        const double ip = 1.0 / piv;
+        double fc[3], pr[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) fc[i] = fcol[cur][ty + 16 * i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int c = tx + 16 * j; pr[j] = (c == p ? 1.0 : prow[cur][c]) * ip; }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int r = ty + 16 * i, c = tx + 16 * j;
+                a[i][j] = r == p ? pr[j] : ((c == p ? 0.0 : a[i][j]) - fc[i] * pr[j]);
+                if (c == p + 1) fcol[nxt][r] = a[i][j];
+                if (r == p + 1) prow[nxt][c] = a[i][j];
+            }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < PCG_CN * PCG_CN; i += 256) M[i] = a[i / PCG_CN][i % PCG_CN];
-    if (!ok && threadIdx.x == 0) atomicOr(bad, 1);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[(ty + 16 * i) * PCG_CN + tx + 16 * j] = a[i][j];
+    if (threadIdx.x == 0 && s_bad) atomicOr(bad, 1);
 }
 
 // Second level of the preconditioner (additive two-level Schwarz): the cluster inverses above damp the error inside a
@@ -420,12 +451,25 @@ __host__ __device__ inline void pcg_hat_support(int I, int A, int nfree, int& fi
 // upper triangle of Ac = P^T H P, row-major with pitch ncp: one workgroup per aggregate pair I <= J, thread = keyframe pair
 // (i, j) of the two supports, the 49 sums reduced over the workgroup in a fixed order (the ranks of a sharded solve must get
 // the same bits).  Column 6 of keyframe i's 6 x 7 basis W_i is (0, 0, 0, t_i - c_I): svec holds t_i, cen the aggregate centres.
+// (the grid runs over the aggregate pairs that hold at least one block -- `pairs`, made once per call by k_pcg_coarse_mark and the
+// host: 1 in 8 of the upper triangle at config 5; as a full nagg x nagg grid the kernel flooded the chip from the side stream for
+// 0.26 ms per trial, and the PCG's 1024-thread workgroups starved behind its small ones)
+__global__ __launch_bounds__(256) void k_pcg_coarse_mark(const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb, int nfree, int nagg, uint8_t* __restrict__ aggmap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb) return;
+    const int A = PCG_CL * pcg_agg_clusters(nfree);
+    const PcgHat ha = pcg_hat(blk_row[i], A, nagg), hb = pcg_hat(blk_col[i], A, nagg);
+    const int ia[2] = { ha.i0, ha.i1 }, ib[2] = { hb.i0, hb.i1 };
+    for (int x = 0; x < 2; x++)
+        for (int y = 0; y < 2; y++) aggmap[min(ia[x], ib[y]) * nagg + max(ia[x], ib[y])] = 1;
+}
 __global__ __launch_bounds__(256) void k_pcg_coarse_build(const double* __restrict__ Hb, const uint8_t* __restrict__ map, const int* __restrict__ id,
                                                           int nfree, int nagg, int ncp, const double* __restrict__ svec, const double* __restrict__ cen,
-                                                          double* __restrict__ Ac)
+                                                          const int* __restrict__ pairs, double* __restrict__ Ac)
 {
     __shared__ double red[4][PCG_CDOF * PCG_CDOF];
-    const int I = blockIdx.y, J = blockIdx.x;
+    const int I = pairs[2 * blockIdx.x], J = pairs[2 * blockIdx.x + 1];
     if (J < I) return;
     const int A = PCG_CL * pcg_agg_clusters(nfree);
     int i0, i1, j0, j1;
@@ -824,7 +868,7 @@ __global__ __launch_bounds__(64) void k_pcg_init_fin(const double* __restrict__ 
     for (int i = 0; i < nblk; i++) { rz += part[3 * i]; bb += part[3 * i + 1]; }
     for (int i = 0; i < ncpart; i++) rzc += cpart[i];
     rz += rzc;
-    sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0; sc[8] = rz; sc[9] = rz;
+    sc[0] = rz; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = -1.0; sc[8] = rz; sc[9] = rz;      // (the direction call of the start-up adds 1)
 }
 
 // Ap = A p, one workgroup per block row (p comes from k_pcg_direction).
@@ -958,6 +1002,357 @@ __global__ __launch_bounds__(64) void k_pcg_scalars(int nblk, const double* __re
     sc[0] = rz; sc[2] = rr; if (pap < sc[3]) sc[3] = pap; sc[4] += 1.0;
 }
 
+// ---------------------------------------------------------------------------------------- pipelined PCG (round 3)
+// The classic iteration above is four dependent grid-wide steps (mat-vec | p.Ap -> update, P^T r | coarse mat-vec | prolongation,
+// direction): the two dot products and the two halves of the coarse level each force a kernel boundary, and at 2000 keyframes
+// every one of the four kernels is a latency floor (5-15 us), not a bandwidth problem.  The pipelined form of Ghysels & Vanroose
+// (Parallel Computing 40, 2014, Alg. 4) applies the preconditioner and the matrix to w = A u instead of r, which decouples them
+// from the dot products:
+//     gamma = (r, u), delta = (w, u)                      (partials left by the previous iteration's row kernel)
+//     m = M^-1 w;  nn = A m
+//     beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)          (first iteration: beta = 0, alpha = gamma / delta)
+//     z = nn + beta z;  q = m + beta q;  s = w + beta s;  p = u + beta p
+//     x += alpha p;  r -= alpha s;  u -= alpha q;  w -= alpha z
+// which is TWO kernels per iteration:
+//   k_ppcg_prec  one workgroup per 32 keyframes: m = Minv_cluster w + P Aci (P^T w).  Every workgroup sums the per-keyframe
+//                contributions to P^T w (left by the row kernel in `CA`, one coalesced pass) and multiplies the rows of Aci that its
+//                own <= PCG_PSLOTS aggregates need -- redundant work out of L2 instead of two more grid-wide steps.  One extra
+//                workgroup reduces the dot-product partials and publishes alpha, beta for the row kernel.
+//   k_ppcg_row   one workgroup per block row: nn = A m from the row-contiguous copy of the matrix (`Hf`: both triangles, entries of
+//                a row side by side, transposition done once per LM trial by k_ppcg_expand instead of in every iteration), then
+//                the eight vector updates of its six unknowns, the partial dot products and the contributions to P^T w_new.
+// Measured on config 5 (optimize(20), 518 iterations): 27.3 us per iteration inside a graph (row kernel 14.5: it streams the 66 MB of
+// Hf at 5.3 TB/s out of the Infinity Cache; k_ppcg_prec 12.8: 0.5 MB per workgroup through ONE CU's path to L2) against 37 us for the
+// four classic kernels.  A variant with one workgroup per CLUSTER of 8 keyframes (mat-vec, updates, cluster level of M^-1 and the
+// cluster's pre-summed share of P^T w in one kernel, which shrinks what the second kernel reads from 0.5 MB to 0.18 MB per
+// workgroup) was built and measured slower: 23.3 + 8.2 us -- 250 workgroups of 1024 threads leave one workgroup per CU, and
+// nothing overlaps its barriers and its serial tail, where four 256-thread workgroups per CU overlap each other.
+// In exact arithmetic the iterates are those of the classic method; in floating point the recurrences for u and w drift, and the
+// true residual stalls near 1e-9 |b| (tools/gba_pipelined_study.py: identical iteration counts at 1e-6 and 1e-9 on a late trial
+// of config 5, floor 2e-9) -- so solves asked for more than 1e-7 keep the classic kernels (ba_host.cpp decides).
+// Vector slots of the state buffer (n doubles each):
+enum { PV_X = 0, PV_R, PV_U, PV_W, PV_P, PV_S, PV_Q, PV_Z, PV_M, PV_COUNT };
+// scalars: sc[0] gamma, sc[1] |b|^2, sc[2] |r|^2, sc[3] min (p, A p) seen, sc[4] iterations, sc[5] alpha, sc[6] beta
+
+// Hf[k][36] = block of entry k of the symmetric row lists, as the row sees it (transposed where the stored block is the mirror
+// image); ecol[k] = its block column.  One thread per element; padding entries (sorted to the end) are skipped.
+__global__ __launch_bounds__(256) void k_ppcg_expand(const double* __restrict__ Hb, const unsigned* __restrict__ ent_key, const unsigned* __restrict__ ent_val,
+                                                     int n_ent, int nfree, double* __restrict__ Hf, int* __restrict__ ecol)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i >= 36LL * n_ent) return;
+    const int k = (int)(i / 36), e = (int)(i - 36LL * k), r = e / 6, c = e - 6 * r;
+    const unsigned key = ent_key[k];
+    if (key == 0xFFFFFFFFu) return;
+    const unsigned v = ent_val[k];
+    const double* B = Hb + 36LL * (v & 0x7FFFFFFFu);
+    Hf[i] = (v & 0x80000000u) ? B[c * 6 + r] : B[r * 6 + c];
+    if (e == 0) ecol[k] = (int)(key % (unsigned)nfree);
+}
+
+// contribution of keyframe f's six values v[0..5] (lanes d = 0..5 hold v[d], lane 6 forms the scale product) to the restricted
+// vector: CA[s][7 I + d], s = f - first keyframe of aggregate I's support; called by 7 consecutive lanes with d = 0..6
+__device__ __forceinline__ void ppcg_contribute(int f, int d, double vd, double v3, double v4, double v5, int nfree, int nagg, int ncp,
+                                                const double* __restrict__ svec, const double* __restrict__ cen, double* __restrict__ CA)
+{
+    const int A = PCG_CL * pcg_agg_clusters(nfree);
+    const PcgHat h = pcg_hat(f, A, nagg);
+    double t0 = 0, t1 = 0, t2 = 0;
+    if (d == 6) { t0 = svec[3LL * f]; t1 = svec[3LL * f + 1]; t2 = svec[3LL * f + 2]; }
+    {
+        const int first = max(0, A * h.i0 - A / 2);
+        double val = vd;
+        if (d == 6) { const double* c = cen + 3 * h.i0; val = ((t0 - c[0]) * v3 + (t1 - c[1]) * v4) + (t2 - c[2]) * v5; }
+        CA[(long long)(f - first) * ncp + PCG_CDOF * h.i0 + d] = h.w0 * val;
+    }
+    if (h.i1 != h.i0) {
+        const int first = max(0, A * h.i1 - A / 2);
+        double val = vd;
+        if (d == 6) { const double* c = cen + 3 * h.i1; val = ((t0 - c[0]) * v3 + (t1 - c[1]) * v4) + (t2 - c[2]) * v5; }
+        CA[(long long)(f - first) * ncp + PCG_CDOF * h.i1 + d] = h.w1 * val;
+    }
+}
+
+// start of a solve: x = 0, r = b, the direction vectors zero, P^T r contributions; the last workgroup sums |b|^2 and sets the scalars
+__global__ __launch_bounds__(256) void k_ppcg_init(const double* __restrict__ b, int nfree, double* __restrict__ wb, int nagg, int ncp,
+                                                   const double* __restrict__ svec, const double* __restrict__ cen, double* __restrict__ CA, double* __restrict__ sc)
+{
+    const long long n = 6LL * nfree;
+    const int nb32 = (nfree + PCG_UPD_KF - 1) / PCG_UPD_KF;
+    if ((int)blockIdx.x == nb32) {
+        __shared__ double red[4];
+        double s = 0;
+#pragma unroll 8
+        for (long long i = threadIdx.x; i < n; i += 256) s += b[i] * b[i];
+        for (int st = 32; st >= 1; st >>= 1) s += __shfl_xor(s, st, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double bb = ((red[0] + red[1]) + red[2]) + red[3];
+            sc[0] = 0.0; sc[1] = bb; sc[2] = bb; sc[3] = 1e300; sc[4] = 0.0; sc[5] = 1.0; sc[6] = 0.0;
+        }
+        return;
+    }
+    __shared__ double rs[PCG_UPD_TPB];
+    const long long o = (long long)blockIdx.x * PCG_UPD_TPB + threadIdx.x;
+    if (threadIdx.x < PCG_UPD_TPB) {
+        const double ri = o < n ? b[o] : 0.0;
+        rs[threadIdx.x] = ri;
+        if (o < n) {
+            wb[PV_X * n + o] = 0.0; wb[PV_R * n + o] = ri; wb[PV_P * n + o] = 0.0; wb[PV_S * n + o] = 0.0; wb[PV_Q * n + o] = 0.0; wb[PV_Z * n + o] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (CA && threadIdx.x < PCG_UPD_KF * PCG_CDOF) {
+        const int k = threadIdx.x / PCG_CDOF, d = threadIdx.x - PCG_CDOF * k, f = blockIdx.x * PCG_UPD_KF + k;
+        if (f < nfree) ppcg_contribute(f, d, d < 6 ? rs[6 * k + d] : 0.0, rs[6 * k + 3], rs[6 * k + 4], rs[6 * k + 5], nfree, nagg, ncp, svec, cen, CA);
+    }
+}
+
+// out = M^-1 in  (vector slots of wb);  Aci == nullptr: cluster level alone.  The extra last workgroup (do_scalars) turns the
+// row kernel's partials into gamma, delta, |r|^2 and publishes alpha, beta.
+// The kernel is a latency problem (64 workgroups, ~0.5 MB each out of L2): a workgroup has 1024 threads and EVERY global load of a
+// thread is requested before the first is used -- the rows of Aci (they do not depend on P^T in), the columns of the cluster
+// inverses and the CA rows -- so the whole preconditioner costs about two L2 round trips plus the time 0.5 MB take through one CU's
+// path to L2.  Partial sums meet in LDS and are added in a fixed order.
+#define PCG_PSLOTS (PCG_UPD_KF / (PCG_CL * PCG_AGG) + 2)       // aggregates a block of PCG_UPD_KF keyframes can touch
+#define PP_TPB 1024
+#define PP_NW (PP_TPB / 64)
+#define PP_CQ 4                                                // a column of CA is summed by PP_CQ threads (a quarter of the support rows each)
+#define PP_MQ 4                                                // an unknown's cluster product by PP_MQ threads (PCG_CN / PP_MQ terms each)
+#define PP_COLS 4                                              // columns of CA per thread: PP_COLS * (PP_TPB / PP_CQ) >= coarse pitch
+#define PP_D2 8                                                // 16-byte pieces of an Aci row per lane: 128 * PP_D2 >= coarse pitch
+#define PP_ROWS_PER_WAVE ((PCG_PSLOTS * PCG_CDOF + PP_NW - 1) / PP_NW)
+static_assert(PCG_CN % PP_MQ == 0 && PP_MQ * PCG_UPD_TPB <= PP_TPB, "cluster product split");
+__host__ __device__ inline bool ppcg_prec_fits(int ncp, int agg_keyframes)
+{ return ncp <= PP_COLS * (PP_TPB / PP_CQ) && ncp <= 128 * PP_D2 && (2 * agg_keyframes) % PP_CQ == 0 && PCG_UPD_KF / agg_keyframes + 2 <= PCG_PSLOTS; }
+__global__ __launch_bounds__(PP_TPB) void k_ppcg_prec(const double* __restrict__ Minv, int nfree, double* __restrict__ wb, int in_slot, int out_slot,
+                                                      const double* __restrict__ Aci, int nc, int ncp, const double* __restrict__ CA, int nagg,
+                                                      const double* __restrict__ svec, const double* __restrict__ cen,
+                                                      const double* __restrict__ part, double* __restrict__ sc, int do_scalars)
+{
+    const long long n = 6LL * nfree;
+    const int nb32 = (nfree + PCG_UPD_KF - 1) / PCG_UPD_KF;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x == nb32) {
+        if (!do_scalars) return;
+        __shared__ double red[3][PP_NW];
+        double g = 0, dl = 0, rr = 0;
+        for (int i = threadIdx.x; i < nfree; i += PP_TPB) { g += part[3 * i]; dl += part[3 * i + 1]; rr += part[3 * i + 2]; }
+        for (int st = 32; st >= 1; st >>= 1) { g += __shfl_xor(g, st, 64); dl += __shfl_xor(dl, st, 64); rr += __shfl_xor(rr, st, 64); }
+        if (lane == 0) { red[0][wv] = g; red[1][wv] = dl; red[2][wv] = rr; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            g = dl = rr = 0;
+            for (int w2 = 0; w2 < PP_NW; w2++) { g += red[0][w2]; dl += red[1][w2]; rr += red[2][w2]; }          // wave order: fixed
+            const double it = sc[4], g_old = sc[0], a_old = sc[5];
+            double beta = 0.0, den = dl;
+            if (it > 0.0) { beta = g_old != 0.0 ? g / g_old : 0.0; den = dl - beta * g / a_old; }
+            // den = (p, A p) in exact arithmetic: not positive = the system (or the preconditioner) is not positive definite, or the
+            // recurrences have broken down; the host looks at sc[3] and abandons the solve
+            double alpha = den > 0.0 ? g / den : 0.0;
+            if (!(g > 0.0) && rr > 0.0) den = -1.0;
+            if (!(den >= sc[3])) sc[3] = den;                    // (also catches NaN)
+            if (alpha == 0.0) alpha = 1e-300;                     // keeps the next iteration's division finite; the solve is abandoned anyway
+            sc[0] = g; sc[2] = rr; sc[4] = it + 1.0; sc[5] = alpha; sc[6] = beta;
+        }
+        return;
+    }
+    extern __shared__ double pp_lds[];                     // rc[ncp] (P^T in), cpart[PP_CQ][ncp]
+    __shared__ double ws[PCG_UPD_TPB], mpart[PP_MQ][PCG_UPD_TPB], yl[PCG_PSLOTS * PCG_CDOF];
+    double* rc = pp_lds;
+    double* cpart = pp_lds + ncp;
+    const int f0 = blockIdx.x * PCG_UPD_KF;
+    const int A = PCG_CL * pcg_agg_clusters(nfree);
+    typedef double pp_d2 __attribute__((ext_vector_type(2)));
+    // ---- every load of this thread, requested back to back
+    // (1) rows of Aci: wave wv takes rows wv, wv + PP_NW, ... of the block's 7 * nsl
+    int ibase = 0, nrows = 0;
+    pp_d2 arow[PP_ROWS_PER_WAVE][PP_D2];
+    if (Aci) {
+        ibase = pcg_hat(f0, A, nagg).i0;
+        nrows = PCG_CDOF * min(PCG_PSLOTS, nagg - ibase);
+#pragma unroll
+        for (int q = 0; q < PP_ROWS_PER_WAVE; q++) {
+            const int row = min(wv + PP_NW * q, nrows - 1);
+            const pp_d2* R = reinterpret_cast<const pp_d2*>(Aci + (long long)(PCG_CDOF * ibase + row) * ncp);
+#pragma unroll
+            for (int k = 0; k < PP_D2; k++) { const int c2 = lane + 64 * k; arow[q][k] = 2 * c2 < ncp ? R[c2] : pp_d2{0.0, 0.0}; }
+        }
+    }
+    // (2) cluster inverse: thread (unknown u, quarter mq) takes PCG_CN / PP_MQ terms of the unknown's column
+    const int mu = threadIdx.x % PCG_UPD_TPB, mq = threadIdx.x / PCG_UPD_TPB;
+    const long long mo = (long long)f0 * 6 + mu;
+    const bool mlive = mq < PP_MQ && mo < n;
+    double mv[PCG_CN / PP_MQ];
+    if (mlive) {
+        const int cl = (int)(mo / PCG_CN), li = (int)(mo - (long long)cl * PCG_CN);
+        const double* M = Minv + (long long)cl * PCG_CN * PCG_CN + li + (long long)(mq * (PCG_CN / PP_MQ)) * PCG_CN;
+#pragma unroll
+        for (int k = 0; k < PCG_CN / PP_MQ; k++) mv[k] = M[k * PCG_CN];          // symmetric: column li read with unit stride across lanes
+    }
+    if (threadIdx.x < PCG_UPD_TPB) ws[threadIdx.x] = mo < n ? wb[(long long)in_slot * n + mo] : 0.0;
+    // (3) P^T in: thread (column group, quarter cq) sums its quarter of the 2 A support rows of up to PP_COLS columns
+    if (Aci) {
+        const int cq = threadIdx.x / (PP_TPB / PP_CQ), cj = threadIdx.x % (PP_TPB / PP_CQ);
+        const int rq = (2 * A) / PP_CQ;                                           // rows per quarter
+        double cs[PP_COLS];
+#pragma unroll
+        for (int k = 0; k < PP_COLS; k++) {
+            const int j = cj + (PP_TPB / PP_CQ) * k;
+            double s = 0.0;
+            if (j < ncp) {
+                const double* col = CA + (long long)(cq * rq) * ncp + j;
+#pragma unroll 8
+                for (int q = 0; q < rq; q++) s += col[(long long)q * ncp];
+            }
+            cs[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < PP_COLS; k++) { const int j = cj + (PP_TPB / PP_CQ) * k; if (j < ncp) cpart[cq * ncp + j] = cs[k]; }
+    }
+    __syncthreads();
+    if (Aci)
+        for (int j = threadIdx.x; j < ncp; j += PP_TPB) rc[j] = j < nc ? ((cpart[j] + cpart[ncp + j]) + cpart[2 * ncp + j]) + cpart[3 * ncp + j] : 0.0;      // quarters in row order: ascending keyframe
+    if (mlive) {
+        const int base = (mu / PCG_CN) * PCG_CN + mq * (PCG_CN / PP_MQ);
+        double z = 0.0;
+#pragma unroll
+        for (int k = 0; k < PCG_CN / PP_MQ; k++) z += mv[k] * ws[base + k];
+        mpart[mq][mu] = z;
+    }
+    __syncthreads();
+    if (Aci) {
+#pragma unroll
+        for (int q = 0; q < PP_ROWS_PER_WAVE; q++) {
+            const int row = wv + PP_NW * q;
+            double sa = 0.0;
+#pragma unroll
+            for (int k = 0; k < PP_D2; k++) { const int c2 = lane + 64 * k; if (2 * c2 < ncp) sa += arow[q][k].x * rc[2 * c2] + arow[q][k].y * rc[2 * c2 + 1]; }
+            for (int st = 32; st >= 1; st >>= 1) sa += __shfl_xor(sa, st, 64);
+            if (lane == 0 && row < nrows) yl[row] = sa;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < PCG_UPD_TPB && mo < n) {
+        double z = ((mpart[0][mu] + mpart[1][mu]) + mpart[2][mu]) + mpart[3][mu];
+        if (Aci) {
+            const int f = (int)(mo / 6), d = (int)(mo - 6LL * f);
+            const PcgHat h = pcg_hat(f, A, nagg);
+            const double* y0 = yl + PCG_CDOF * (h.i0 - ibase); const double* y1 = yl + PCG_CDOF * (h.i1 - ibase);
+            double v = h.w0 * y0[d] + h.w1 * y1[d];
+            if (d >= 3) {
+                const double t = svec[3LL * f + (d - 3)];
+                v += h.w0 * ((t - cen[3 * h.i0 + (d - 3)]) * y0[6]) + h.w1 * ((t - cen[3 * h.i1 + (d - 3)]) * y1[6]);
+            }
+            z += v;
+        }
+        wb[(long long)out_slot * n + mo] = z;
+    }
+}
+
+// One workgroup per block row.  MODE 0 (start of a solve): w = A u, partials of (r, u), (w, u), (r, r), contributions of w.
+// MODE 1: nn = A m, then the recurrences above for the row's six unknowns, the same partials and contributions for the new r, u, w.
+// EPS = entries per thread and step: 4 (<= 128 registers, 4 workgroups per CU: two rounds of workgroups at 2000 keyframes) or
+// 2 (<= 64 registers: every workgroup of a 2000-keyframe map resident at once, two steps for the average row)
+template <int MODE, int EPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPS == 2 ? 8 : 4, EPS == 2 ? 8 : 4))) void k_ppcg_row(
+    const double* __restrict__ Hf, const int* __restrict__ ecol, const int* __restrict__ row_ptr, int nfree, double* __restrict__ wb, const double* __restrict__ sc,
+    double* __restrict__ part, double* __restrict__ CA, int nagg, int ncp, const double* __restrict__ svec, const double* __restrict__ cen)
+{
+    __shared__ double red[42][6];
+    // block rows are dealt to the XCDs in contiguous ranges (workgroups go round-robin over the 8 XCDs)
+    const int rows_per_xcd = (nfree + PCG_XCDS - 1) / PCG_XCDS;
+    const int row = ((int)blockIdx.x % PCG_XCDS) * rows_per_xcd + (int)blockIdx.x / PCG_XCDS;
+    if (row >= nfree) return;
+    const long long n = 6LL * nfree;
+    const double* xin = wb + (long long)(MODE == 0 ? PV_U : PV_M) * n;
+    const int slot = threadIdx.x / 6, r = threadIdx.x - 6 * slot;
+    typedef double pr_d2 __attribute__((ext_vector_type(2)));
+    const long long o = 6LL * row + threadIdx.x;
+    double acc = 0;
+    if (slot < 42) {
+        const int k_end = row_ptr[2 * row + 1];
+        for (int k0 = row_ptr[2 * row] + slot; k0 < k_end; k0 += EPS * 42) {
+            pr_d2 bv[EPS][3]; int col[EPS];
+#pragma unroll
+            for (int q = 0; q < EPS; q++) {
+                const int k = k0 + 42 * q;
+                col[q] = -1;
+#pragma unroll
+                for (int c = 0; c < 3; c++) bv[q][c] = pr_d2{0.0, 0.0};
+                if (k < k_end) {
+                    col[q] = ecol[k];
+                    const pr_d2* B = reinterpret_cast<const pr_d2*>(Hf + 36LL * k + 6 * r);
+                    bv[q][0] = B[0]; bv[q][1] = B[1]; bv[q][2] = B[2];
+                }
+            }
+            pr_d2 xv[EPS][3];
+#pragma unroll
+            for (int q = 0; q < EPS; q++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) xv[q][c] = pr_d2{0.0, 0.0};
+                if (col[q] >= 0) {
+                    const pr_d2* X = reinterpret_cast<const pr_d2*>(xin + 6LL * col[q]);
+                    xv[q][0] = X[0]; xv[q][1] = X[1]; xv[q][2] = X[2];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < EPS; q++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { acc += bv[q][c].x * xv[q][c].x; acc += bv[q][c].y * xv[q][c].y; }
+        }
+    }
+    // the epilogue's operands (lanes 0..5 of wave 0 own the row's six unknowns) are requested here, behind the mat-vec's loads -- held
+    // across the loop they cost 20 registers and a wave per SIMD -- and arrive while the workgroup meets at the barrier
+    double alpha = 0, beta = 0, vz = 0, vq = 0, vs = 0, vp = 0, vx = 0, vr = 0, vu = 0, vw = 0, vm = 0;
+    if (threadIdx.x < 6) {
+        vr = wb[PV_R * n + o]; vu = wb[PV_U * n + o];
+        if (MODE == 1) {
+            alpha = sc[5]; beta = sc[6];
+            vz = wb[PV_Z * n + o]; vq = wb[PV_Q * n + o]; vs = wb[PV_S * n + o]; vp = wb[PV_P * n + o];
+            vx = wb[PV_X * n + o]; vw = wb[PV_W * n + o]; vm = wb[PV_M * n + o];
+        }
+    }
+    if (slot < 42) red[slot][r] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double g = 0, dl = 0, rr = 0, wn = 0;
+        if (threadIdx.x < 6) {
+            double tot = 0;
+            for (int s2 = 0; s2 < 42; s2++) tot += red[s2][threadIdx.x];
+            if (MODE == 0) {
+                wn = tot;
+                wb[PV_W * n + o] = wn;
+            } else {
+                vz = tot + beta * vz; vq = vm + beta * vq; vs = vw + beta * vs; vp = vu + beta * vp;
+                vx += alpha * vp; vr -= alpha * vs; vu -= alpha * vq; wn = vw - alpha * vz;
+                wb[PV_Z * n + o] = vz; wb[PV_Q * n + o] = vq; wb[PV_S * n + o] = vs; wb[PV_P * n + o] = vp;
+                wb[PV_X * n + o] = vx; wb[PV_R * n + o] = vr; wb[PV_U * n + o] = vu; wb[PV_W * n + o] = wn;
+            }
+            g = vr * vu; dl = wn * vu; rr = vr * vr;
+        }
+        for (int st = 4; st >= 1; st >>= 1) { g += __shfl_xor(g, st, 64); dl += __shfl_xor(dl, st, 64); rr += __shfl_xor(rr, st, 64); }   // lanes 0..7 (6, 7 hold 0)
+        if (threadIdx.x == 0) { part[3 * row] = g; part[3 * row + 1] = dl; part[3 * row + 2] = rr; }
+        if (CA) {
+            const double w3 = __shfl(wn, 3, 64), w4 = __shfl(wn, 4, 64), w5 = __shfl(wn, 5, 64);
+            if (threadIdx.x < PCG_CDOF) ppcg_contribute(row, threadIdx.x, wn, w3, w4, w5, nfree, nagg, ncp, svec, cen, CA);
+        }
+    }
+}
+
+// |r|^2 of the current iterate for the host (the row kernel leaves partials; the next k_ppcg_prec would reduce them one iteration late)
+__global__ __launch_bounds__(256) void k_ppcg_publish(const double* __restrict__ part, int nfree, double* __restrict__ sc)
+{
+    __shared__ double red[4];
+    double rr = 0;
+    for (int i = threadIdx.x; i < nfree; i += 256) rr += part[3 * i + 2];
+    for (int st = 32; st >= 1; st >>= 1) rr += __shfl_xor(rr, st, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = rr;
+    __syncthreads();
+    if (threadIdx.x == 0) sc[2] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 // ---------------------------------------------------------------------------------------- host wrappers
 static inline int nblk(long long n, int b) { return (int)((n + b - 1) / b); }
 
@@ -1051,11 +1446,19 @@ int pcg_coarse_dim(int nfree) { return PCG_CDOF * pcg_coarse_aggregates(nfree); 
 int pcg_coarse_pitch(int nfree) { return nblk(pcg_coarse_dim(nfree), INV_B) * INV_B; }
 int pcg_coarse_parts(int nfree) { return nblk(pcg_coarse_dim(nfree), 4); }
 // Ac = P^T H P as a full (padded) matrix in `Ac`
-void pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, const double* svec, const double* cen, double* Ac)
+void pcg_launch_coarse_mark(hipStream_t s, const int* blk_row, const int* blk_col, int nb, int nfree, uint8_t* aggmap)
+{
+    if (nb > 0) hipLaunchKernelGGL(k_pcg_coarse_mark, dim3(nblk(nb, 256)), dim3(256), 0, s, blk_row, blk_col, nb, nfree, pcg_coarse_aggregates(nfree), aggmap);
+}
+hipError_t pcg_launch_coarse_build(hipStream_t s, const double* Hb, const uint8_t* map, const int* id, int nfree, const double* svec, const double* cen,
+                                   const int* pairs, int npairs, double* Ac)
 {
     const int nagg = pcg_coarse_aggregates(nfree), nc = PCG_CDOF * nagg, ncp = pcg_coarse_pitch(nfree);
-    hipLaunchKernelGGL(k_pcg_coarse_build, dim3(nagg, nagg), dim3(256), 0, s, Hb, map, id, nfree, nagg, ncp, svec, cen, Ac);
+    hipError_t e = hipMemsetAsync(Ac, 0, (size_t)ncp * ncp * sizeof(double), s);          // aggregate pairs without a block stay zero
+    if (e != hipSuccess) return e;
+    if (npairs > 0) hipLaunchKernelGGL(k_pcg_coarse_build, dim3(npairs), dim3(256), 0, s, Hb, map, id, nfree, nagg, ncp, svec, cen, pairs, Ac);
     hipLaunchKernelGGL(k_pcg_coarse_complete, dim3(nblk((long long)ncp * ncp, 256)), dim3(256), 0, s, Ac, nc, ncp);
+    return hipSuccess;
 }
 void pcg_launch_coarse_mirror(hipStream_t s, double* A, int ncp)
 {
@@ -1099,6 +1502,55 @@ void pcg_launch_iter(hipStream_t s, const double* Hb, const int* row_ptr, const 
 void pcg_launch_publish(hipStream_t s, int nfree, double* part, double* sc, const PcgCoarse& C)
 {
     hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(64), 0, s, nblk(6LL * nfree, PCG_UPD_TPB), part, C.cpart, C.Aci ? pcg_coarse_parts(nfree) : 0, sc);
+}
+
+// ---- pipelined PCG: host wrappers
+bool ppcg_supported(int nfree) { return ppcg_prec_fits(pcg_coarse_pitch(nfree), pcg_coarse_agg_keyframes(nfree)); }
+size_t ppcg_state_doubles(int nfree) { return (size_t)PV_COUNT * 6 * (size_t)nfree; }
+size_t ppcg_ca_doubles(int nfree) { return (size_t)2 * pcg_coarse_agg_keyframes(nfree) * (size_t)pcg_coarse_pitch(nfree); }
+void ppcg_launch_expand(hipStream_t s, const double* Hb, const unsigned* ekey, const unsigned* eval, int n_ent, int nfree, double* Hf, int* ecol)
+{
+    if (n_ent > 0) hipLaunchKernelGGL(k_ppcg_expand, dim3(nblk(36LL * n_ent, 256)), dim3(256), 0, s, Hb, ekey, eval, n_ent, nfree, Hf, ecol);
+}
+static void ppcg_launch_prec(hipStream_t s, const double* Minv, int nfree, double* wb, int in_slot, int out_slot, const PcgCoarse& C, const PpcgBufs& B,
+                             double* part, double* sc, int do_scalars)
+{
+    const int nb32 = nblk(nfree, PCG_UPD_KF);
+    const int nagg = C.Aci ? pcg_coarse_aggregates(nfree) : 0, nc = PCG_CDOF * nagg, ncp = C.Aci ? pcg_coarse_pitch(nfree) : 0;
+    const size_t lds = (size_t)((1 + PP_CQ) * ncp + 2) * sizeof(double);
+    hipLaunchKernelGGL(k_ppcg_prec, dim3(nb32 + 1), dim3(PP_TPB), lds, s, Minv, nfree, wb, in_slot, out_slot, (const double*)C.Aci, nc, ncp, (const double*)(C.Aci ? B.CA : nullptr), nagg,
+                       C.svec, C.cen, (const double*)part, sc, do_scalars);
+}
+template <int MODE>
+static void ppcg_launch_row(hipStream_t s, const int* row_ptr, int nfree, double* wb, double* part, double* sc, const PcgCoarse& C, const PpcgBufs& B)
+{
+    const int nagg = C.Aci ? pcg_coarse_aggregates(nfree) : 0, ncp = C.Aci ? pcg_coarse_pitch(nfree) : 0;
+    static const int eps = getenv("CCM_PPCG_EPS") ? atoi(getenv("CCM_PPCG_EPS")) : 4;        // measured: see DESIGN.md
+    if (eps == 2) hipLaunchKernelGGL((k_ppcg_row<MODE, 2>), dim3(PCG_XCDS * nblk(nfree, PCG_XCDS)), dim3(256), 0, s, (const double*)B.Hf, (const int*)B.ecol, row_ptr, nfree, wb, (const double*)sc, part,
+                                     C.Aci ? B.CA : nullptr, nagg, ncp, C.svec, C.cen);
+    else hipLaunchKernelGGL((k_ppcg_row<MODE, 4>), dim3(PCG_XCDS * nblk(nfree, PCG_XCDS)), dim3(256), 0, s, (const double*)B.Hf, (const int*)B.ecol, row_ptr, nfree, wb, (const double*)sc, part,
+                            C.Aci ? B.CA : nullptr, nagg, ncp, C.svec, C.cen);
+}
+// x = 0, r = b, u = M^-1 r, w = A u and the first partials
+hipError_t ppcg_launch_init(hipStream_t s, const double* b, const double* Minv, const int* row_ptr, int nfree, double* wb, double* part, double* sc,
+                            const PcgCoarse& C, const PpcgBufs& B)
+{
+    const int nagg = C.Aci ? pcg_coarse_aggregates(nfree) : 0, ncp = C.Aci ? pcg_coarse_pitch(nfree) : 0;
+    double* CA = C.Aci ? B.CA : nullptr;
+    if (CA) { hipError_t e = hipMemsetAsync(CA, 0, ppcg_ca_doubles(nfree) * sizeof(double), s); if (e != hipSuccess) return e; }   // support rows past a map's ends stay zero
+    hipLaunchKernelGGL(k_ppcg_init, dim3(nblk(nfree, PCG_UPD_KF) + 1), dim3(256), 0, s, b, nfree, wb, nagg, ncp, C.svec, C.cen, CA, sc);
+    ppcg_launch_prec(s, Minv, nfree, wb, PV_R, PV_U, C, B, part, sc, 0);
+    ppcg_launch_row<0>(s, row_ptr, nfree, wb, part, sc, C, B);
+    return hipSuccess;
+}
+void ppcg_launch_iter(hipStream_t s, const double* Minv, const int* row_ptr, int nfree, double* wb, double* part, double* sc, const PcgCoarse& C, const PpcgBufs& B)
+{
+    ppcg_launch_prec(s, Minv, nfree, wb, PV_W, PV_M, C, B, part, sc, 1);
+    ppcg_launch_row<1>(s, row_ptr, nfree, wb, part, sc, C, B);
+}
+void ppcg_launch_publish(hipStream_t s, const double* part, int nfree, double* sc)
+{
+    hipLaunchKernelGGL(k_ppcg_publish, dim3(1), dim3(256), 0, s, part, nfree, sc);
 }
 
 // Reduced systems of a local BA (config 4: 20 free keyframes, n = 120 unknowns) are solved by ONE workgroup in one launch: L L^T

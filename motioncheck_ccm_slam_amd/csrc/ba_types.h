@@ -37,3 +37,10 @@ struct PcgCoarse {
     const double* svec;            // [nfree][3] keyframe translations at the start of the call (the scale columns of P)
     const double* cen;             // [aggregates][3] mean translation of an aggregate's own keyframes
 };
+
+// buffers of the pipelined PCG (ba_sparse.hip, k_ppcg_*)
+struct PpcgBufs {
+    double* Hf;                    // [row entries][36] the reduced matrix with both triangles, a row's blocks side by side
+    int* ecol;                     // [row entries] block column
+    double* CA;                    // [2 A][coarse pitch] per-keyframe contributions to the restricted vector, by position in the aggregate's support
+};

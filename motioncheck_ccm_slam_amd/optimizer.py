@@ -16,8 +16,8 @@ import numpy as np
 from . import _lib
 from ._lib import BaOptions, BaProblem, BaResult
 
-TH_HUBER_2D_GLOBAL = float(np.sqrt(5.99))    # src/Optimizer.cpp:81, :712
-TH_HUBER_2D_LOCAL = float(np.sqrt(5.991))    # src/Optimizer.cpp:468
+TH_HUBER_2D_GLOBAL = float(np.float32(np.sqrt(5.99)))    # src/Optimizer.cpp:81, :712 (`const float thHuber2D = sqrt(5.99)`: rounded to float)
+TH_HUBER_2D_LOCAL = float(np.float32(np.sqrt(5.991)))    # src/Optimizer.cpp:468 (`const float thHuberMono`)
 CHI2_MONO = 5.991                            # src/Optimizer.cpp:556, :582
 
 
@@ -55,7 +55,7 @@ def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None, pcg_tol
                 chi2_final=res.chi2_final, lambda_final=res.lambda_final, stopped=bool(res.stopped),
                 t_linearize=res.t_linearize, t_schur=res.t_schur, t_solve=res.t_solve, t_update=res.t_update,
                 schur_blocks=res.schur_blocks, schur_pairs=res.schur_pairs, pcg_iterations=res.pcg_iterations,
-                pcg_fallbacks=res.pcg_fallbacks)
+                pcg_fallbacks=res.pcg_fallbacks, pcg_pipelined=res.pcg_pipelined)
 
 
 class Optimizer:

@@ -17,8 +17,9 @@ namespace ccm_shim {
 // their own thread in the reference (src/ClientHandler.cpp:140-176), and a ccm_ctx is not meant to be shared.
 inline ccm_ctx* ctx()
 {
-    static thread_local ccm_ctx* c = ccm_create(0, 0);
-    return c;
+    // a shim object built against another version of ccm_hot.h than the library would pass structures of the wrong size
+    static thread_local ccm_ctx* c = ccm_abi_version() == CCM_ABI_VERSION ? ccm_create(0, 0) : nullptr;
+    return c;                                          // nullptr: every ccm_* call returns CCM_E_ARG and the shim bodies throw
 }
 
 // per-feature vocabulary node of a DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>), -1 = none

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.ccm_abi_version() == 1
+    assert lib.ccm_abi_version() == 3 == _lib.ABI_VERSION
 
 
 def test_tables_match_oracle(oracle):

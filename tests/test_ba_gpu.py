@@ -17,7 +17,7 @@ TOL = 1e-5
 def test_local_ba_config4(ctx, oracle):
     g = synth.local_ba_graph()
     r = Optimizer.LocalBundleAdjustmentClient(g, ctx=ctx)
-    ref = oracle.ba_solve(g, 5, np.sqrt(5.991), 10)
+    ref = oracle.ba_solve(g, 5, float(np.float32(np.sqrt(5.991))), 10)
     assert pose_delta(r["poses"], ref["poses"]).max() <= TOL
     assert np.abs(r["points"] - ref["points"]).max() <= 1e-6
     assert r["iterations_done"] == ref["iterations_done"] and r["trials"] == ref["trials"]
@@ -27,7 +27,7 @@ def test_local_ba_config4(ctx, oracle):
     assert pose_delta(r["poses"], z["poses"]).max() <= TOL
     # stage results: the first stage alone (5 robust iterations) also agrees
     r1 = Optimizer.BundleAdjustmentClient({**g}, 5, ctx=ctx)
-    ref1 = oracle.ba_solve(g, 5, np.sqrt(5.99))
+    ref1 = oracle.ba_solve(g, 5, float(np.float32(np.sqrt(5.99))))
     assert pose_delta(r1["poses"], ref1["poses"]).max() <= TOL
     # fixed keyframes never move
     fx = g["fixed"].astype(bool)
@@ -38,7 +38,7 @@ def test_gba_small_and_medium(ctx, oracle):
     for kf, pts, its in ((60, 3000, 20), (240, 20000, 6)):
         g = synth.gba_graph(n_kf=kf, n_points=pts, n_agents=3, seed=kf)
         r = Optimizer.MapFusionGBA(g, its, ctx=ctx)
-        ref = oracle.ba_solve(g, its, np.sqrt(5.99))
+        ref = oracle.ba_solve(g, its, float(np.float32(np.sqrt(5.99))))
         assert pose_delta(r["poses"], ref["poses"]).max() <= TOL
         assert r["iterations_done"] == ref["iterations_done"]
         assert np.isclose(r["chi2_final"], ref["chi2_final"], rtol=1e-8)
@@ -97,7 +97,7 @@ def test_edge_cases(ctx, oracle):
     # every keyframe fixed: only the landmarks are refined
     g2 = dict(g); g2["fixed"] = np.ones_like(g["fixed"])
     r = Optimizer.BundleAdjustmentClient(g2, 5, ctx=ctx)
-    ref = oracle.ba_solve(g2, 5, np.sqrt(5.99))
+    ref = oracle.ba_solve(g2, 5, float(np.float32(np.sqrt(5.99))))
     assert (r["poses"] == g["poses"]).all() and np.abs(r["points"] - ref["points"]).max() < 1e-8
     # a landmark seen once and a keyframe without observations
     keep = np.ones(len(g["edge_pose"]), bool)
@@ -106,7 +106,7 @@ def test_edge_cases(ctx, oracle):
     keep[g["edge_pose"] == int(np.flatnonzero(g["fixed"] == 0)[0])] = False
     g3 = {k: (v[keep] if k in ("edge_pose", "edge_point", "obs", "info") else v) for k, v in g.items()}
     r = Optimizer.BundleAdjustmentClient(g3, 5, ctx=ctx)
-    ref = oracle.ba_solve(g3, 5, np.sqrt(5.99))
+    ref = oracle.ba_solve(g3, 5, float(np.float32(np.sqrt(5.99))))
     assert pose_delta(r["poses"], ref["poses"]).max() <= TOL
     with pytest.raises(Exception):
         bad = dict(g); bad["edge_pose"] = g["edge_pose"].copy(); bad["edge_pose"][0] = 999
@@ -226,13 +226,13 @@ from motioncheck_ccm_slam_amd.optimizer import Optimizer, pose_delta
 from oracle import oracle_py as O
 ctx = _lib.Context(0)
 g = synth.local_ba_graph()
-r = Optimizer.LocalBundleAdjustmentClient(g, ctx=ctx); ref = O.ba_solve(g, 5, float(np.sqrt(5.991)), 10)
+r = Optimizer.LocalBundleAdjustmentClient(g, ctx=ctx); ref = O.ba_solve(g, 5, float(np.float32(np.sqrt(5.991))), 10)
 assert r["pcg_iterations"] > 0, "the dense path ran"
 assert pose_delta(r["poses"], ref["poses"]).max() <= 1e-5 and (r["outlier"] == ref["outlier"]).all()
 assert r["iterations_done"] == ref["iterations_done"] and r["trials"] == ref["trials"]
 for kf, pts, its in ((60, 3000, 8), (240, 20000, 4)):
     g = synth.gba_graph(n_kf=kf, n_points=pts, n_agents=3, seed=kf)
-    r = Optimizer.MapFusionGBA(g, its, ctx=ctx); ref = O.ba_solve(g, its, float(np.sqrt(5.99)))
+    r = Optimizer.MapFusionGBA(g, its, ctx=ctx); ref = O.ba_solve(g, its, float(np.float32(np.sqrt(5.99))))
     assert r["pcg_iterations"] > 0 and r["pcg_fallbacks"] == 0
     d = pose_delta(r["poses"], ref["poses"]).max()
     assert d <= 1e-5 and r["iterations_done"] == ref["iterations_done"], (kf, d)
@@ -243,7 +243,7 @@ for kf, pts, its in ((60, 3000, 8), (240, 20000, 4)):
 for lo, hi in ((100, 160), (0, 240)):
     g = synth.gba_graph(n_kf=240, n_points=20000, n_agents=3, seed=7)
     p = np.array(g["poses"], dtype=np.float64); p[lo:hi, 4:7] = p[lo, 4:7]; g = dict(g); g["poses"] = p
-    r = Optimizer.MapFusionGBA(g, 3, ctx=ctx, pcg_tol=1e-13); ref = O.ba_solve(g, 3, float(np.sqrt(5.99)))
+    r = Optimizer.MapFusionGBA(g, 3, ctx=ctx, pcg_tol=1e-13); ref = O.ba_solve(g, 3, float(np.float32(np.sqrt(5.99))))
     assert r["pcg_iterations"] > 0 and r["pcg_fallbacks"] == 0, (lo, hi, r["pcg_fallbacks"])
     assert r["trials"] == ref["trials"] and pose_delta(r["poses"], ref["poses"]).max() <= 1e-7, (lo, hi, pose_delta(r["poses"], ref["poses"]).max())
 print("ok")
@@ -274,7 +274,7 @@ g = synth.gba_graph(n_kf=240, n_points=20000, n_agents=3, seed=240)
 r = Optimizer.MapFusionGBA(g, 4, ctx=ctx)
 if rank == 0:
     from oracle import oracle_py as O
-    ref = O.ba_solve(g, 4, float(np.sqrt(5.99)))
+    ref = O.ba_solve(g, 4, float(np.float32(np.sqrt(5.99))))
     d = pose_delta(r["poses"], ref["poses"]).max()
     dp = np.abs(r["points"] - ref["points"]).max()
     assert d <= 1e-5 and r["iterations_done"] == ref["iterations_done"] and r["trials"] == ref["trials"], (d, r["iterations_done"], ref["iterations_done"], r["trials"], ref["trials"])

@@ -33,14 +33,14 @@ def _worker(rank, world, port, q):
     g = synth.gba_graph(n_kf=24, n_points=900, n_agents=3, seed=5)
     lam = 0.37
     sub = D.subgraph_for_rank(g, rank, world)
-    Hs, bs, _ = O.ba_reduced_system(sub, np.sqrt(5.99), 0.0)      # lambda only on the landmark blocks below
-    Hs, bs, _ = O.ba_reduced_system(sub, np.sqrt(5.99), lam)
+    Hs, bs, _ = O.ba_reduced_system(sub, float(np.float32(np.sqrt(5.99))), 0.0)      # lambda only on the landmark blocks below
+    Hs, bs, _ = O.ba_reduced_system(sub, float(np.float32(np.sqrt(5.99))), lam)
     n = Hs.shape[0]
     Hs = Hs - lam * np.eye(n)                                      # the pose-diagonal lambda is added once, after the sum
     t = torch.from_numpy(np.concatenate([Hs.ravel(), bs]))
     dist.all_reduce(t)
     Hsum = t[:n * n].numpy().reshape(n, n) + lam * np.eye(n); bsum = t[n * n:].numpy()
-    Hfull, bfull, _ = O.ba_reduced_system(g, np.sqrt(5.99), lam)
+    Hfull, bfull, _ = O.ba_reduced_system(g, float(np.float32(np.sqrt(5.99))), lam)
     err = max(np.abs(Hsum - Hfull).max() / np.abs(Hfull).max(), np.abs(bsum - bfull).max() / np.abs(bfull).max())
     # the ranks' landmark ranges partition the landmarks
     l0, l1 = sub["landmark_range"]

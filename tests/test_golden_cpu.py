@@ -32,7 +32,7 @@ def test_match_fixture(oracle):
 
 def test_ba_fixture(oracle):
     z = np.load(os.path.join(G, "ba_local.npz"))
-    res = oracle.ba_solve(synth.local_ba_graph(), 5, np.sqrt(5.991), 10)
+    res = oracle.ba_solve(synth.local_ba_graph(), 5, float(np.float32(np.sqrt(5.991))), 10)
     assert np.abs(res["poses"] - z["poses"]).max() < 1e-12
     assert np.allclose([res["chi2_initial"], res["chi2_final"]], z["chi2"], rtol=1e-12)
     assert (np.flatnonzero(res["outlier"]) == z["outliers"]).all()

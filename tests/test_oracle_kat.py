@@ -209,7 +209,7 @@ def test_lm_recovers_noise_free_graph(oracle):
 
 def test_huber_continuity(oracle):
     # rho and rho' are continuous at chi2 = delta^2 (robust_kernel_impl.cpp:78-91)
-    d = np.sqrt(5.991)
+    d = float(np.float32(np.sqrt(5.991)))
     lo, hi = 5.991 * (1 - 1e-9), 5.991 * (1 + 1e-9)
     rho_hi = 2 * np.sqrt(hi) * d - d * d
     assert abs(rho_hi - lo) < 1e-6 and abs(d / np.sqrt(hi) - 1.0) < 1e-6
@@ -235,7 +235,7 @@ def test_block_sparse_cholesky_equals_dense_and_numpy(oracle):
     linearisation of a 300-keyframe graph, then whole LM runs with either solver forced."""
     from motioncheck_ccm_slam_amd import synth
     g = synth.gba_graph(n_kf=300, n_points=30000, n_agents=3, seed=8)
-    h = float(np.sqrt(5.99))
+    h = float(np.float32(np.sqrt(5.99)))
     xd, ld, _ = oracle.ba_solve_once(g, h, 10.0, 1)
     xs, ls, st = oracle.ba_solve_once(g, h, 10.0, 2)
     H, b, _ = oracle.ba_reduced_system(g, h, 10.0)

@@ -28,7 +28,7 @@ a, b = synth.descriptor_pair(0)
 bi, bd, sd = O.hamming_match(a, b)
 np.savez_compressed(os.path.join(out, "match_pair0.npz"), best_idx=bi.astype(np.int16), best_dist=bd.astype(np.int16), second_dist=sd.astype(np.int16))
 g = synth.local_ba_graph()
-res = O.ba_solve(g, 5, np.sqrt(5.991), 10)
+res = O.ba_solve(g, 5, float(np.float32(np.sqrt(5.991))), 10)
 np.savez_compressed(os.path.join(out, "ba_local.npz"), poses=res["poses"], points_head=res["points"][:64],
                     chi2=np.array([res["chi2_initial"], res["chi2_final"]]), outliers=np.flatnonzero(res["outlier"]).astype(np.int32),
                     iterations=np.array([res["iterations_done"], res["trials"]]))

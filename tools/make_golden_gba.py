@@ -17,7 +17,7 @@ import scipy.sparse as sp
 from motioncheck_ccm_slam_amd import synth
 from oracle import oracle_py as O
 
-HUBER = float(np.sqrt(5.99))            # src/Optimizer.cpp:712
+HUBER = float(np.float32(np.sqrt(5.99)))            # src/Optimizer.cpp:712
 ITERS = 5
 POINT_STRIDE = 40
 

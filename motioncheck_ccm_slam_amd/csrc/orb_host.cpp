@@ -98,6 +98,7 @@ struct OrbState {
     OrbGeom geom{};
     std::vector<OrbCell> cells;
     std::vector<OrbBand> bands; size_t band_lds = 0; bool fused = true; int surv_cap = 1024; hipStream_t copy_stream = nullptr; hipEvent_t copy_done = nullptr;
+    hipStream_t down_stream = nullptr; hipEvent_t chunk_done = nullptr;      // results of a chunk go down while the next chunk is extracted
     DevBuf geom_dev, cells_dev, tables_dev, bands_dev;
     DevBuf pyr, smap, slots, cell_count, keysA, keysB, sel, sel_count, status;
     DevBuf img0;                   // staging for the host-pointer entry point
@@ -115,6 +116,8 @@ void orb_state_free(OrbState* s)
     for (DevBuf* b : all) b->release();
     if (s->copy_done) (void)hipEventDestroy(s->copy_done);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    if (s->chunk_done) (void)hipEventDestroy(s->chunk_done);
+    if (s->down_stream) (void)hipStreamDestroy(s->down_stream);
     delete s;
 }
 
@@ -410,24 +413,48 @@ int ccm_orb_extract(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img, int
     CCM_HIP(c, hipSetDevice(c->device));
     if (!c->orb) c->orb = new OrbState();
     OrbState& S = *c->orb;
-    const int pitch = (int)align_up(w, 64);
-    const size_t plane = (size_t)pitch * h;
-    CCM_RESERVE(c, S.img0, plane * n_images);
+    // Device layout of level 0: rows padded to 64 bytes (a strided 2-D copy), or -- when the caller's rows are 16-byte multiples, which
+    // is all the kernels' wide loads need -- the caller's own layout, so that a chunk of frames goes up as ONE linear copy.
+    // Only for batches that go up in chunks behind the extraction: a single 752 x 480 frame is extracted 26 us faster from 64-byte
+    // aligned rows (0.214 against 0.240 ms per call), which a batch hides behind its uploads.
+    static const bool force_2d = getenv("CCM_ORB_UPLOAD_2D") && atoi(getenv("CCM_ORB_UPLOAD_2D")) != 0;
+    static const int chunk_frames = getenv("CCM_ORB_CHUNK") ? std::max(1, atoi(getenv("CCM_ORB_CHUNK"))) : 64;
+    const int n_chunks = n_images >= 2 * chunk_frames ? (n_images + chunk_frames - 1) / chunk_frames : 1;
+    const bool linear = !force_2d && n_chunks > 1 && stride % 16 == 0 && image_stride % 16 == 0 && image_stride >= (size_t)stride * h;
+    const int pitch = linear ? stride : (int)align_up(w, 64);
+    const size_t plane = linear ? image_stride : (size_t)pitch * h;
+    CCM_RESERVE(c, S.img0, plane * n_images + 64);
     int rc = orb_prepare(c, p, w, h, n_images, max_per_image);
     if (rc) return rc;
     // Host buffers: the frames go up in chunks on a copy stream while the previous chunk is being extracted (the
     // upload is ~2/3 of the whole call for 752x480 frames).  Small batches go up in one piece.
-    static const int chunk_frames = getenv("CCM_ORB_CHUNK") ? std::max(1, atoi(getenv("CCM_ORB_CHUNK"))) : 64;
-    const int n_chunks = n_images >= 2 * chunk_frames ? (n_images + chunk_frames - 1) / chunk_frames : 1;
     if (n_chunks > 1 && !S.copy_stream) {
         CCM_HIP(c, hipStreamCreateWithFlags(&S.copy_stream, hipStreamNonBlocking));
         CCM_HIP(c, hipEventCreateWithFlags(&S.copy_done, hipEventDisableTiming));
     }
     const bool contiguous = n_images == 1 || image_stride == (size_t)stride * h;
+    // Results: with page-locked destination buffers (hipHostMalloc / ccm_host_register) each chunk's keypoints, descriptors and counts
+    // go down on a stream of their own while the next chunk is extracted -- the two copy directions use different engines.  A copy to
+    // pageable memory holds the calling thread until it is done, which would keep it from enqueueing the next chunk: those go down
+    // in one piece at the end (ccm_orb_fetch), as before.
+    auto page_locked = [](const void* q) {
+        if (!q) return true;
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    const bool stream_down = n_chunks > 1 && (kps || desc || counts) && page_locked(kps) && page_locked(desc) && page_locked(counts);
+    if (stream_down && !S.down_stream) {
+        CCM_HIP(c, hipStreamCreateWithFlags(&S.down_stream, hipStreamNonBlocking));
+        CCM_HIP(c, hipEventCreateWithFlags(&S.chunk_done, hipEventDisableTiming));
+    }
     for (int ck = 0; ck < n_chunks; ck++) {
         const int f0 = (int)((long long)n_images * ck / n_chunks), f1 = (int)((long long)n_images * (ck + 1) / n_chunks);
         hipStream_t up = n_chunks > 1 ? S.copy_stream : c->stream;
-        if (contiguous) {
+        if (linear) {
+            const size_t bytes = f1 < n_images ? plane * (f1 - f0) : plane * (f1 - 1 - f0) + (size_t)stride * (h - 1) + w;     // (the last image may end with its last pixel)
+            CCM_HIP(c, hipMemcpyAsync(S.img0.as<char>() + plane * f0, img + image_stride * f0, bytes, hipMemcpyHostToDevice, up));
+        } else if (contiguous) {
             // rows of consecutive images are consecutive in both layouts (device plane == pitch * h)
             CCM_HIP(c, hipMemcpy2DAsync(S.img0.as<char>() + plane * f0, pitch, img + image_stride * f0, stride, w, (size_t)h * (f1 - f0),
                                         hipMemcpyHostToDevice, up));
@@ -441,6 +468,18 @@ int ccm_orb_extract(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img, int
         }
         rc = orb_run(c, S.img0.as<uint8_t>(), pitch, plane, f0, f1 - f0);
         if (rc) return rc;
+        if (stream_down) {
+            const size_t m = (size_t)S.max_per_image, nf = (size_t)(f1 - f0);
+            CCM_HIP(c, hipEventRecord(S.chunk_done, c->stream));
+            CCM_HIP(c, hipStreamWaitEvent(S.down_stream, S.chunk_done, 0));
+            if (kps) CCM_HIP(c, hipMemcpyAsync(kps + f0 * m, S.kps.as<ccm_keypoint>() + f0 * m, nf * m * sizeof(ccm_keypoint), hipMemcpyDeviceToHost, S.down_stream));
+            if (desc) CCM_HIP(c, hipMemcpyAsync(desc + f0 * m * 32, S.desc.as<uint8_t>() + f0 * m * 32, nf * m * 32, hipMemcpyDeviceToHost, S.down_stream));
+            if (counts) CCM_HIP(c, hipMemcpyAsync(counts + f0, S.counts.as<int32_t>() + f0, nf * 4, hipMemcpyDeviceToHost, S.down_stream));
+        }
+    }
+    if (stream_down) {
+        CCM_HIP(c, hipStreamSynchronize(S.down_stream));
+        return orb_check_status(c);                          // (synchronises the context's stream and reads the kernels' status word)
     }
     return ccm_orb_fetch(c, kps, desc, counts);
 }

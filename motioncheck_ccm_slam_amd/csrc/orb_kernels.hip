@@ -1440,6 +1440,9 @@ void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* c
     // algorithmic bytes) but the kernel, which is not bandwidth-bound, runs 3-5 % slower with every co-locating order tried
     // (profiles/r02_xcd_order.txt); k_orient_desc gains from it and uses it
     static const int xcd_on = getenv("CCM_ORB_XCD_FC") ? atoi(getenv("CCM_ORB_XCD_FC")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 0);
+    // occupancy experiment (tools/r03_occupancy_sweep.sh): a larger LDS request leaves fewer workgroups per CU; results are unchanged
+    static const size_t lds_min = getenv("CCM_FC_LDS_MIN") ? (size_t)atol(getenv("CCM_FC_LDS_MIN")) : 0;
+    if (lds_bytes < lds_min) lds_bytes = lds_min;
     if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
     else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
 }
@@ -1456,6 +1459,7 @@ void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_fra
                             int* status)
 {
     static const int xcd_on = getenv("CCM_ORB_XCD_OD") ? atoi(getenv("CCM_ORB_XCD_OD")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 1);
-    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + OD_WAVES - 1) / OD_WAVES, nframes), dim3(64 * OD_WAVES), 0, s,
+    static const size_t lds_pad = getenv("CCM_OD_LDS_PAD") ? (size_t)atol(getenv("CCM_OD_LDS_PAD")) : 0;     // occupancy experiment only
+    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + OD_WAVES - 1) / OD_WAVES, nframes), dim3(64 * OD_WAVES), lds_pad, s,
                        g_dev, sel, sel_count, kps, desc, counts, max_per_image, status, xcd_on);
 }

@@ -62,12 +62,19 @@ class ORBextractor:
         n = int(counts[0])
         return kps[0, :n].copy(), desc[0, :n].copy()
 
-    def extract_batch(self, images: np.ndarray):
-        """images [B,H,W] uint8 (host) -> kps [B,max], desc [B,max,32], counts [B]."""
+    def extract_batch(self, images: np.ndarray, out=None):
+        """images [B,H,W] uint8 (host) -> kps [B,max], desc [B,max,32], counts [B].  `out` = (kps, desc, counts) of those shapes
+        re-uses the caller's buffers (a server keeps its frame and result pools page-locked with Context.host_register: the results
+        of a chunk of frames then go down while the next chunk is extracted)."""
         images = np.ascontiguousarray(images, np.uint8)
         b, h, w = images.shape
         m = self.max_per_image
-        kps = np.zeros((b, m), KP_DTYPE); desc = np.zeros((b, m, 32), np.uint8); counts = np.zeros(b, "i4")
+        if out is not None:
+            kps, desc, counts = out
+            assert kps.shape == (b, m) and kps.dtype == KP_DTYPE and desc.shape == (b, m, 32) and desc.dtype == np.uint8 and counts.shape == (b,) and counts.dtype == np.int32
+            assert kps.flags.c_contiguous and desc.flags.c_contiguous and counts.flags.c_contiguous
+        else:
+            kps = np.zeros((b, m), KP_DTYPE); desc = np.zeros((b, m, 32), np.uint8); counts = np.zeros(b, "i4")
         self.ctx.check(self.lib.ccm_orb_extract(self.ctx.handle, C.byref(self.par), _lib.ptr(images), w, h, w,
                                                 C.c_size_t(w * h), b, _lib.ptr(kps), _lib.ptr(desc), _lib.ptr(counts), m))
         self._last = (b, w, h)

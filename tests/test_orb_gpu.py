@@ -120,6 +120,17 @@ def test_full_batch_properties(ctx, oracle):
     par = oracle.default_params()
     for f in (0, 37, 101, 200, 255):
         _same(kps[f, :counts[f]], desc[f, :counts[f]], oracle.orb_extract(par, imgs[f]))
+    # page-locked frame and result pools: every chunk's results go down on a stream of their own while the next chunk is
+    # extracted (round 3) -- the same bytes must arrive, the pad rows included
+    pool = (np.zeros_like(kps), np.zeros_like(desc), np.zeros_like(counts))
+    for a in pool + (imgs,):
+        ctx.host_register(a)
+    try:
+        k3, d3, c3 = ex.extract_batch(imgs, out=pool)
+        assert k3 is pool[0] and (c3 == counts).all() and (k3 == kps).all() and (d3 == desc).all()
+    finally:
+        for a in pool + (imgs,):
+            ctx.host_unregister(a)
 
 
 @pytest.mark.parametrize("env", [{"CCM_ORB_FUSED": "0"}, {"CCM_FC_PACKED": "0"}, {"CCM_ORB_CHUNK": "2"}, {"CCM_BF_VARIANT": "0"}])

@@ -320,9 +320,15 @@ def main():
             E = len(g["edge_pose"])
             # the map's edge arrays are page-locked once, as a server that keeps its graph buffers would (ccm_host_register);
             # three timed calls, the median is reported (pageable uploads were seen to take 1.5 or 19 ms from call to call)
+            Optimizer.MapFusionGBA(g, 1, ctx=ctx)                       # warm-up (allocations, graph capture)
+            # the same call from pageable edge arrays first (what a caller that does not page-lock its graph buffers gets): five calls, all reported
+            pageable = []
+            if world == 1:
+                for _ in range(5):
+                    tg = time.perf_counter(); Optimizer.MapFusionGBA(g, args.gba_iters, ctx=ctx); pageable.append(round(time.perf_counter() - tg, 4))
             for k in ("edge_pose", "edge_point", "obs", "info"):
                 ctx.host_register(g[k])
-            Optimizer.MapFusionGBA(g, 1, ctx=ctx)                       # warm-up (allocations, graph capture)
+            Optimizer.MapFusionGBA(g, 1, ctx=ctx)
             fence()
             calls = []
             for _ in range(3):
@@ -343,6 +349,7 @@ def main():
                    "iter_per_s_lm_loop_only": round(r["iterations_done"] / lm_s, 3),
                    "iterations": r["iterations_done"], "iterations_requested": args.gba_iters, "trials": r["trials"],
                    "call_seconds": round(call_s, 4), "call_seconds_all": [round(c[0], 4) for c in calls], "timed_calls": "3, median reported",
+                   "call_seconds_pageable_all": pageable,
                    "lm_seconds": round(lm_s, 4),
                    "setup_seconds": round(call_s - lm_s, 4),
                    "setup_note": "graph upload (edge arrays page-locked by the caller), edge-list check and index on the device, pair enumeration, radix sorts, block pattern, PCG graph capture, result download",
@@ -352,8 +359,10 @@ def main():
                    "schur_blocks": r["schur_blocks"], "schur_pairs_this_rank": r["schur_pairs"], "pcg_iterations": r["pcg_iterations"],
                    "chi2_initial": r["chi2_initial"], "chi2_final": r["chi2_final"], "n_gpus": world, "scaling": "strong",
                    "dtype": "f64",
-                   "reduced_solve": "PCG (cluster + coarse level), relative residual 1e-6 per trial (ccm_ba_options.pcg_tol default; final poses "
-                                    "within 1e-8 of the exact-solve oracle on this graph, contract 1e-5: tests/test_ba_gpu.py)"}
+                   "pcg_pipelined": r.get("pcg_pipelined", 0), "pcg_fallbacks": r["pcg_fallbacks"],
+                   "reduced_solve": "pipelined PCG (Ghysels-Vanroose: two kernels per iteration), cluster + coarse level, relative residual 1e-6 per trial "
+                                    "(ccm_ba_options.pcg_tol default; final poses within 1e-8 of the exact-solve oracle on this graph, contract 1e-5: "
+                                    "tests/test_ba_gpu.py)"}
             # per-phase roofline figures of this rank: a second call with the library's event profiling on (HIP events on its stream)
             ctx.profile(True)
             rp = Optimizer.MapFusionGBA(g, 5, ctx=ctx)
@@ -362,7 +371,7 @@ def main():
             fixed = np.asarray(g["fixed"]).astype(bool)
             k_free = np.bincount(g["edge_point"][~fixed[g["edge_pose"]]], minlength=len(g["points"])).astype(np.float64)
             schur_flops = float((2.0 * (9 + 72 * k_free + 54 * k_free * (k_free + 1)) + 60).sum()) / world      # this rank's share
-            roof = {"from": "HIP events of a 5-iteration call of this run (ccm_profile_*); rocprofv3 PMC of the same kernels: profiles/r02*_gba_*"}
+            roof = {"from": "HIP events of a 5-iteration call of this run (ccm_profile_*); rocprofv3 traces and PMC of the same kernels: profiles/r03*_gba_*, profiles/r02*_gba_*"}
             ms_s, n_s = pr["k_sp_schur_blocks"]
             if n_s:
                 tf = schur_flops / (ms_s / n_s * 1e-3) / 1e12
@@ -380,11 +389,12 @@ def main():
             if rp["pcg_iterations"]:
                 per_it = rp["t_solve"] / rp["pcg_iterations"]
                 spmv_bytes = (2 * r["schur_blocks"] - 1999) * 288.0
-                roof["solve"] = {"kernels": "k_pcg_spmv + k_pcg_update + k_pcg_coarse + k_pcg_direction (HIP graphs)", "bound": "hbm",
+                roof["solve"] = {"kernels": ("k_ppcg_prec + k_ppcg_row (HIP graphs)" if rp.get("pcg_pipelined") else
+                                             "k_pcg_spmv + k_pcg_update + k_pcg_coarse + k_pcg_direction (HIP graphs)"), "bound": "hbm",
                                  "us_per_pcg_iteration_host_timed": round(per_it * 1e6, 2),
                                  "spmv_algorithmic_bytes": int(spmv_bytes), "achieved": round(spmv_bytes / per_it / 1e9, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(spmv_bytes / per_it / 1e9 / HBM_PEAK_GBS, 5),
-                                 "note": "whole PCG iteration (four kernels + host round trips) charged to the mat-vec's bytes"}
+                                 "note": "whole PCG iteration (its kernels, the per-trial set-up and the host round trips) charged to the mat-vec's bytes"}
             gba["roofline"] = roof
             if solo:
                 # BASELINE config 4 beside it: the local BA Mapping runs per keyframe (20 free + 10 fixed keyframes, 5000 points, 5 robust + 10

@@ -112,7 +112,6 @@ void ba_state_free(BaState* s)
     if (s->ev_inv) (void)hipEventDestroy(s->ev_inv);
     if (s->ev_copy) (void)hipEventDestroy(s->ev_copy);
     for (hipEvent_t e : s->clock_ev) (void)hipEventDestroy(e);
-    if (s->side) (void)hipStreamDestroy(s->side);
     if (s->pinned) (void)hipHostFree(s->pinned);
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
                       &s->obs, &s->info, &s->active, &s->err, &s->pt_first, &s->pose_first, &s->pose_edges, &s->Hpp, &s->bp,
@@ -541,10 +540,9 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     const int nc = nfree > 0 ? pcg_coarse_dim(nfree) : 0, ncp = nfree > 0 ? pcg_coarse_pitch(nfree) : 0;
     if (use_pcg && want_coarse && nc >= 64 && nc <= 2304) {      // beyond: the cubic inversion would outlast an LM trial (more than 24 576 free keyframes)
         if (!S.side) {
-            // lowest priority: the inversion has a whole LM trial to finish, the PCG kernels it shares the GPU with are the critical path
-            int prio_least = 0, prio_greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-            if (hipStreamCreateWithPriority(&S.side, hipStreamNonBlocking, prio_least) != hipSuccess) { S.side = nullptr; return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed"); }
+            // the context's low-priority auxiliary stream: the inversion has a whole LM trial to finish, the PCG kernels it shares the GPU
+            // with are the critical path
+            if (!(S.side = ccm_aux_stream(c, 0))) return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed");
             CCM_HIP(c, hipEventCreateWithFlags(&S.ev_hb, hipEventDisableTiming));
             CCM_HIP(c, hipEventCreateWithFlags(&S.ev_inv, hipEventDisableTiming));
             CCM_HIP(c, hipEventCreateWithFlags(&S.ev_copy, hipEventDisableTiming));

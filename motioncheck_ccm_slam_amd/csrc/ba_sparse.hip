@@ -1026,7 +1026,12 @@ __global__ __launch_bounds__(64) void k_pcg_scalars(int nblk, const double* __re
 // four classic kernels.  A variant with one workgroup per CLUSTER of 8 keyframes (mat-vec, updates, cluster level of M^-1 and the
 // cluster's pre-summed share of P^T w in one kernel, which shrinks what the second kernel reads from 0.5 MB to 0.18 MB per
 // workgroup) was built and measured slower: 23.3 + 8.2 us -- 250 workgroups of 1024 threads leave one workgroup per CU, and
-// nothing overlaps its barriers and its serial tail, where four 256-thread workgroups per CU overlap each other.
+// nothing overlaps its barriers and its serial tail, where four 256-thread workgroups per CU overlap each other.  Two rows per
+// 512-thread workgroup with their contributions to P^T w added up before they are stored (half the CA rows for k_ppcg_prec to
+// read) lost for the same reason: 19.4 against 17.7 ms of solve time per optimize(20).  A stop flag on the device (kernels return at
+// once when |r|^2 has reached the tolerance, the host keeps one chunk of iterations enqueued ahead of what it has seen: no GPU idle
+// time in the host's round trips, exact iteration counts 498 instead of 518) measured the same 17.6-18.2 ms: the round trips are
+// not what costs, as round 2 had found for the classic iteration.
 // In exact arithmetic the iterates are those of the classic method; in floating point the recurrences for u and w drift, and the
 // true residual stalls near 1e-9 |b| (tools/gba_pipelined_study.py: identical iteration counts at 1e-6 and 1e-9 on a late trial
 // of config 5, floor 2e-9) -- so solves asked for more than 1e-7 keep the classic kernels (ba_host.cpp decides).

@@ -13,6 +13,17 @@ int ccm_fail(ccm_ctx* c, int code, const char* fmt, ...)
     return code;
 }
 
+hipStream_t ccm_aux_stream(ccm_ctx* c, int which)
+{
+    if (!c || which < 0 || which > 1) return nullptr;
+    if (!c->aux[which]) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&c->aux[which], hipStreamNonBlocking, which == 0 ? least : 0) != hipSuccess) { c->aux[which] = nullptr; (void)hipGetLastError(); }
+    }
+    return c->aux[which];
+}
+
 extern "C" {
 
 int ccm_abi_version(void) { return CCM_ABI_VERSION; }
@@ -43,6 +54,7 @@ void ccm_destroy(ccm_ctx* c)
     sim3_state_free(c->sim3);
     ess_state_free(c->ess);
     for (ProfLabel& L : c->prof) for (auto& e : L.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (hipStream_t& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

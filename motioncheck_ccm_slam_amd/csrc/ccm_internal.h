@@ -25,6 +25,13 @@ struct ccm_ctx {
     ProfLabel prof[CCM_PROF_COUNT];
     int device = 0;
     hipStream_t stream = nullptr;
+    // Two auxiliary streams per context, created on first use and SHARED by its subsystems (ccm_aux_stream below): the runtime maps
+    // streams onto a handful of hardware queues (4 by default), and streams that share a queue run one after the other -- when the
+    // extractor's copy streams and the bundle adjustment's side stream were separate objects, the fifth stream of the process put the
+    // coarse inversion into the PCG's queue and the solve took 30 instead of 18 ms (round 3).
+    //   aux[0]  lowest priority: the extractor's uploads, the bundle adjustment's coarse inversion
+    //   aux[1]  default priority: the extractor's downloads
+    hipStream_t aux[2] = { nullptr, nullptr };
     std::string err;
     OrbState* orb = nullptr;
     MatchState* match = nullptr;
@@ -53,6 +60,7 @@ struct DevBuf {
 };
 
 int ccm_fail(ccm_ctx* c, int code, const char* fmt, ...);
+hipStream_t ccm_aux_stream(ccm_ctx* c, int which);      // nullptr if it cannot be created
 
 #define CCM_HIP(c, expr)                                                                   \
     do {                                                                                   \

@@ -115,9 +115,7 @@ void orb_state_free(OrbState* s)
                       &s->keysA, &s->keysB, &s->sel, &s->sel_count, &s->status, &s->img0, &s->kps, &s->desc, &s->counts };
     for (DevBuf* b : all) b->release();
     if (s->copy_done) (void)hipEventDestroy(s->copy_done);
-    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     if (s->chunk_done) (void)hipEventDestroy(s->chunk_done);
-    if (s->down_stream) (void)hipStreamDestroy(s->down_stream);
     delete s;
 }
 
@@ -429,7 +427,7 @@ int ccm_orb_extract(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img, int
     // Host buffers: the frames go up in chunks on a copy stream while the previous chunk is being extracted (the
     // upload is ~2/3 of the whole call for 752x480 frames).  Small batches go up in one piece.
     if (n_chunks > 1 && !S.copy_stream) {
-        CCM_HIP(c, hipStreamCreateWithFlags(&S.copy_stream, hipStreamNonBlocking));
+        if (!(S.copy_stream = ccm_aux_stream(c, 0))) return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed");      // (the context's, shared)
         CCM_HIP(c, hipEventCreateWithFlags(&S.copy_done, hipEventDisableTiming));
     }
     const bool contiguous = n_images == 1 || image_stride == (size_t)stride * h;
@@ -445,7 +443,7 @@ int ccm_orb_extract(ccm_ctx* c, const ccm_orb_params* p, const uint8_t* img, int
     };
     const bool stream_down = n_chunks > 1 && (kps || desc || counts) && page_locked(kps) && page_locked(desc) && page_locked(counts);
     if (stream_down && !S.down_stream) {
-        CCM_HIP(c, hipStreamCreateWithFlags(&S.down_stream, hipStreamNonBlocking));
+        if (!(S.down_stream = ccm_aux_stream(c, 1))) return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed");
         CCM_HIP(c, hipEventCreateWithFlags(&S.chunk_done, hipEventDisableTiming));
     }
     for (int ck = 0; ck < n_chunks; ck++) {

@@ -29,8 +29,17 @@ def test_bench_single_gpu_line():
     assert d["gba"]["iterations"] == 2 and d["gba"]["chi2_final"] < d["gba"]["chi2_initial"]
 
 
+@pytest.fixture(scope="module")
+def gba_single():
+    """config 5, two LM iterations, unsharded: what the sharded runs below must reproduce"""
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--gba-iters", "2", "--no-cpu", "--no-extra"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return _line(out.stdout)["gba"]
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
-def test_bench_ranks_rehearsal(ranks):
+def test_bench_ranks_rehearsal(ranks, gba_single):
     """bench.py under torch.distributed.run with 2 and 4 ranks sharing the one GPU (gloo control plane, shared-memory
     all-reduce in RCCL's place): the N > 1 flow, the landmark shards and the rank-0 increment with several silent ranks."""
     env = dict(os.environ, CCM_BENCH_BACKEND="gloo", CCM_BENCH_COMM="shm")
@@ -44,3 +53,7 @@ def test_bench_ranks_rehearsal(ranks):
     g = d["gba"]
     assert "error" not in g and g["n_gpus"] == ranks and g["iterations"] == 2 and g["chi2_final"] < g["chi2_initial"]
     assert g["schur_pairs_this_rank"] < 1.2 / ranks * 9190009            # each rank enumerates about its share of the pairs
+    # the sharded solve at FULL size against the unsharded one: the landmark partition only changes the order of the sums
+    assert g["trials"] == gba_single["trials"] and g["iterations"] == gba_single["iterations"] and g["schur_blocks"] == gba_single["schur_blocks"]
+    assert abs(g["chi2_initial"] - gba_single["chi2_initial"]) <= 1e-9 * gba_single["chi2_initial"]
+    assert abs(g["chi2_final"] - gba_single["chi2_final"]) <= 1e-9 * gba_single["chi2_final"], (g["chi2_final"], gba_single["chi2_final"])

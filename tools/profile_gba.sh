@@ -4,7 +4,7 @@
 set -e
 tag=$1; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_gba_kt -- python3 $R/tools/bench_gba.py > $O/${tag}_gba_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_gba_kt -- python3 $R/tools/bench_gba.py --iters 20 > $O/${tag}_gba_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${tag}_gba_fetch -- python3 $R/tools/bench_gba.py --iters 2 > $O/${tag}_gba_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${tag}_gba_write -- python3 $R/tools/bench_gba.py --iters 2 > $O/${tag}_gba_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/${tag}_gba_sq -- python3 $R/tools/bench_gba.py --iters 2 > $O/${tag}_gba_sq.log 2>&1

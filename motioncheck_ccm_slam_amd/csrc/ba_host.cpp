@@ -28,7 +28,7 @@ int comm_allreduce_f64(ccm_ctx* c, double* dev, size_t n, bool max_op);
 void ba_launch_pose_rt(hipStream_t, const BaDev&);
 int ba_errors_blocks(const BaDev&);
 void ba_launch_errors(hipStream_t, const BaDev&, double hd, double* partial, double* out);
-void ba_launch_linearize(hipStream_t, const BaDev&, double hd);
+void ba_launch_linearize(hipStream_t, const BaDev&, double hd, double lambda);
 int comm_allreduce_u8_max(ccm_ctx* c, uint8_t* dev, size_t n);
 // ba_sparse.hip
 size_t sp_scan_temp_bytes(size_t n);
@@ -46,10 +46,10 @@ void sp_launch_pair_block(hipStream_t, const unsigned* key, const int* id, long 
 void sp_launch_seg_bounds(hipStream_t, const unsigned* sk, long long np, int* st, int* en);
 void sp_launch_row_entries(hipStream_t, const int* br, const int* bc, int nb, int nfree, unsigned* key, unsigned* val);
 void sp_launch_row_ptr(hipStream_t, const unsigned* skey, int n_ent, int nfree, int* row_ptr);
-void sp_launch_dinv(hipStream_t, const BaDev&, double lambda, double* Y, double* db);
+void sp_launch_dinv(hipStream_t, const BaDev&, double lambda);
 void sp_launch_schur_blocks(hipStream_t, const BaDev&, const double* Y, const unsigned long long* pairs, const int* st, const int* en,
                             const int* br, const int* bc, int nb, double* Hb);
-void sp_launch_bschur(hipStream_t, const BaDev&, const double* db, double* bs);
+void sp_launch_bschur(hipStream_t, const BaDev&, double* bs);
 void sp_launch_add_lambda(hipStream_t, const int* diag, int nfree, double lambda, double* Hb);
 void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs);
 int dense_small_max();
@@ -102,7 +102,7 @@ struct BaState {
            pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
            partial, scal, flags, info_dev, tmp_ll, pp_diag, gather,
            sp_cnt, sp_off, sp_key, sp_val, sp_key2, sp_val2, sp_map, sp_id, sp_tmp, blk_row, blk_col, diag_id, seg_start, seg_end,
-           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw, pcg_svec, pcg_hf, pcg_ecol, pcg_ca, pcg_aggmap, pcg_pairs;
+           ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw, pcg_svec, pcg_hf, pcg_ecol, pcg_ca, pcg_aggmap, pcg_pairs, ce;
 };
 void ba_state_free(BaState* s)
 {
@@ -119,7 +119,7 @@ void ba_state_free(BaState* s)
                       &s->partial, &s->scal, &s->flags, &s->info_dev, &s->tmp_ll, &s->pp_diag, &s->gather,
                       &s->sp_cnt, &s->sp_off, &s->sp_key, &s->sp_val, &s->sp_key2, &s->sp_val2, &s->sp_map, &s->sp_id, &s->sp_tmp, &s->blk_row,
                       &s->blk_col, &s->diag_id, &s->seg_start, &s->seg_end, &s->ent_key, &s->ent_val, &s->ent_key2, &s->ent_val2, &s->row_ptr,
-                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc, &s->pcg_aci, &s->pcg_coarse, &s->pcg_acw, &s->pcg_svec, &s->pcg_hf, &s->pcg_ecol, &s->pcg_ca, &s->pcg_aggmap, &s->pcg_pairs };
+                      &s->Hb, &s->Y, &s->db, &s->Minv, &s->pcg_w, &s->pcg_pap, &s->pcg_part, &s->pcg_sc, &s->pcg_aci, &s->pcg_coarse, &s->pcg_acw, &s->pcg_svec, &s->pcg_hf, &s->pcg_ecol, &s->pcg_ca, &s->pcg_aggmap, &s->pcg_pairs, &s->ce };
     for (DevBuf* b : all) b->release();
     delete s;
 }
@@ -527,6 +527,8 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         CCM_HIP(c, hipGetLastError());
     }
     CCM_RESERVE(c, S.Y, std::max<size_t>(18 * (size_t)E * 8, 16)); CCM_RESERVE(c, S.db, std::max<size_t>(3 * (size_t)L * 8, 16));
+    CCM_RESERVE(c, S.ce, std::max<size_t>(6 * (size_t)E * 8, 16));
+    D.Z = S.Y.as<double>(); D.db = S.db.as<double>(); D.ce = S.ce.as<double>();
     double* Hb = S.Hb.as<double>();
     D.bs = nfree > 0 ? Hb + 36 * (size_t)nb : nullptr;
     res->schur_blocks = nb; res->schur_pairs = NP;
@@ -704,7 +706,11 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
             if ((rc = eval_chi2(huber, false, 0, &currentChi, nullptr))) return rc;
             const double iniChi = currentChi;
             if (first_eval) { res->chi2_initial = currentChi; first_eval = false; }
-            { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_linearize(st, D, huber); }       // buildSystem
+            // buildSystem.  From the second iteration on lambda is known here, and the landmarks' share of the first trial's Schur step
+            // (Dinv, db, Z, ce) is computed by the same kernel
+            const bool fused_schur = it > 0 && nfree > 0 && lambda > 0;
+            { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_linearize(st, D, huber, fused_schur ? lambda : 0.0); }
+            bool landmark_share_ready = fused_schur;
             if (it == 0) {                                                          // computeLambdaInit
                 ba_launch_diag(st, D, S.tmp_ll.as<double>(), S.pp_diag.as<double>(), scal + 5);
                 if (L == 0) CCM_HIP(c, hipMemsetAsync(scal + 5, 0, 8, st));
@@ -737,11 +743,12 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                 bool dense_info_pending = false;
                 auto t2 = t1;
                 if (nfree > 0) {
-                    { ProfScope ps(c, CCM_PROF_BA_DINV_Y); sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>()); }
+                    if (!landmark_share_ready) { ProfScope ps(c, CCM_PROF_BA_DINV_Y); sp_launch_dinv(st, D, lambda); }
+                    landmark_share_ready = false;                          // a repeated trial has another lambda
                     { ProfScope ps(c, CCM_PROF_BA_SCHUR_BLOCKS);
                       sp_launch_schur_blocks(st, D, S.Y.as<double>(), S.sp_val2.as<unsigned long long>(), S.seg_start.as<int>(), S.seg_end.as<int>(),
                                              S.blk_row.as<int>(), S.blk_col.as<int>(), nb, Hb); }
-                    { ProfScope ps(c, CCM_PROF_BA_BSCHUR); sp_launch_bschur(st, D, S.db.as<double>(), D.bs); }
+                    { ProfScope ps(c, CCM_PROF_BA_BSCHUR); sp_launch_bschur(st, D, D.bs); }
                     if ((rc = comm_allreduce_f64(c, Hb, 36 * (size_t)nb + (size_t)n, false))) return rc;
                     sp_launch_add_lambda(st, S.diag_id.as<int>(), nfree, lambda, Hb);
                     tick(1);
@@ -883,7 +890,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                     }
                 } else {
                     // no free keyframe: only the landmark inverse is needed for the back-substitution
-                    sp_launch_dinv(st, D, lambda, S.Y.as<double>(), S.db.as<double>());
+                    sp_launch_dinv(st, D, lambda);
                     CCM_HIP(c, hipStreamSynchronize(st));
                     tick(1);
                     t2 = clk::now();

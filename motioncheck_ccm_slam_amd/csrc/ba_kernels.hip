@@ -59,8 +59,17 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaDev D, double huber_delta, 
 __global__ __launch_bounds__(256) void k_ba_reduce(const double* __restrict__ in, int n, double* __restrict__ out, int take_max)
 {
     __shared__ double red[256];
-    double acc = take_max ? 0.0 : 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc = take_max ? fmax(acc, fabs(in[i])) : acc + in[i];
+    double acc = 0.0;
+    // eight loads in flight, added in the same order as one by one (the loop was 28 dependent memory round trips at config 5: 20 us)
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = in[i + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = take_max ? fmax(acc, fabs(v[q])) : acc + v[q];
+    }
+    for (; i < n; i += 256) acc = take_max ? fmax(acc, fabs(in[i])) : acc + in[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
@@ -81,8 +90,11 @@ __device__ __forceinline__ double ba_group_sum(double v)
     for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
-template <int G>
-__global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_delta)
+// FUSE (LM iterations after the first, whose lambda is known before the linearisation): the landmark's share of the Schur step rides
+// along -- Dinv = (Hll + lambda I)^-1, db = Dinv b_l, and per edge Z = Hpl L^-T and ce = Hpl db, from the Hpl blocks the group has
+// just written -- instead of k_sp_dinv + k_sp_edge_y re-reading Hll and the 260 MB of Hpl (config 5) in launches of their own.
+template <int G, bool FUSE>
+__global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_delta, double lambda)
 {
     const int gt = blockIdx.x * 256 + threadIdx.x;
     const int l = gt / G, g = gt - l * G;
@@ -119,6 +131,26 @@ __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_d
     if (live && g == 0) {
         for (int i = 0; i < 9; i++) D.Hll[9 * (long long)l + i] = H[i];
         for (int i = 0; i < 3; i++) D.bl[3 * (long long)l + i] = b[i];
+    }
+    if (FUSE && live) {
+        double Dm[9], Di[9], f[6], d[3];
+        for (int i = 0; i < 9; i++) Dm[i] = H[i];
+        Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+        ba_inv3(Dm, Di);
+        d[0] = Di[0] * b[0] + Di[1] * b[1] + Di[2] * b[2];
+        d[1] = Di[3] * b[0] + Di[4] * b[1] + Di[5] * b[2];
+        d[2] = Di[6] * b[0] + Di[7] * b[1] + Di[8] * b[2];
+        ba_chol3(H, lambda, f);
+        if (g == 0) {
+            for (int i = 0; i < 9; i++) D.Dinv[9 * (long long)l + i] = Di[i];
+            for (int i = 0; i < 3; i++) D.db[3 * (long long)l + i] = d[i];
+        }
+        for (int e = e0 + g; e < e1; e += G) {                       // this lane's edges again: their Hpl blocks are its own stores
+            const double* Hx = D.Hpl + 18 * (long long)e;
+            double Bx[18];
+            for (int i = 0; i < 18; i++) Bx[i] = Hx[i];
+            ba_edge_z_c(Bx, f, d, D.Z + 18 * (long long)e, D.ce + 6 * (long long)e);
+        }
     }
 }
 
@@ -313,9 +345,11 @@ void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial,
 #ifndef BA_LM_LANES
 #define BA_LM_LANES 8                     // lanes that share a landmark in k_ba_lin_landmark / k_ba_backsub (measured: see DESIGN.md)
 #endif
-void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd)
+// lambda > 0: the landmarks' share of the Schur step for that lambda is computed along (FUSE above)
+void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd, double lambda)
 {
-    if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_landmark<BA_LM_LANES>, dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D, hd);     // a zero-size grid is a launch error
+    if (D.L > 0 && lambda > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, true>), dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D, hd, lambda);
+    else if (D.L > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, false>), dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D, hd, 0.0);     // a zero-size grid is a launch error
     // few keyframes with long edge lists (local BA): a workgroup per keyframe; maps with thousands of keyframes: a wave each (measured:
     // the workgroup form costs config 5 another 60 us per linearisation, the wave form costs config 4 40 us)
     // (16 waves per keyframe measured no faster than 4 at 20 keyframes x 1300 edges: 22.1 against 21.1 us -- the keyframe's edges are

@@ -135,3 +135,34 @@ BA_HD void ba_inv3(const double* m, double* o)
     o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
     o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
+
+// ---- per-landmark pieces of the Schur step, shared by ba_sparse.hip (k_sp_dinv, k_sp_edge_y) and the fused tail of k_ba_lin_landmark:
+// the same expressions in the same order, so both paths produce the same bits.
+// (ba_inv3 above = Eigen's 3 x 3 inverse by cofactors, what BlockSolver::solve uses for Hll, block_solver.hpp:396)
+// lower Cholesky factor of H + lambda I (upper half of H read): f = { 1/l00, l10, l20, 1/l11, l21, 1/l22 }.
+// Pivots: in exact arithmetic each is >= lambda > 0 (H is a sum of J^T J terms).  For a landmark block that is rank-deficient (one
+// observation, or no parallax) and a late, tiny lambda the computed second or third pivot can round to <= 0, and its square root would
+// poison every reduced block the landmark touches.  A pivot below the rounding level of its own diagonal entry is noise either way, so
+// it is held at that level (2^-52 of the entry): the step stays finite like the reference's, whose 3 x 3 inverse takes no square roots.
+BA_HD void ba_chol3(const double* H, double lambda, double* f)
+{
+    const double d1 = H[4] + lambda, d2 = H[8] + lambda;
+    const double l00 = sqrt(H[0] + lambda), i00 = 1.0 / l00;
+    const double l10 = H[1] * i00, l20 = H[2] * i00;
+    const double l11 = sqrt(fmax(d1 - l10 * l10, 0x1p-52 * d1)), i11 = 1.0 / l11;
+    const double l21 = (H[5] - l20 * l10) * i11;
+    const double i22 = 1.0 / sqrt(fmax(d2 - l20 * l20 - l21 * l21, 0x1p-52 * d2));
+    f[0] = i00; f[1] = l10; f[2] = l20; f[3] = i11; f[4] = l21; f[5] = i22;
+}
+// Z = B L^-T (6 x 3, row z of Z solves z L^T = row of B) and c = B d (6): the per-edge operand of the Schur product and the edge's
+// share of Hpl Dinv b_l
+BA_HD void ba_edge_z_c(const double* B, const double* f, const double* d, double* z, double* c)
+{
+    for (int i = 0; i < 6; i++) {
+        const double z0 = B[i * 3] * f[0];
+        const double z1 = (B[i * 3 + 1] - z0 * f[1]) * f[3];
+        const double z2 = (B[i * 3 + 2] - z0 * f[2] - z1 * f[4]) * f[5];
+        z[i * 3] = z0; z[i * 3 + 1] = z1; z[i * 3 + 2] = z2;
+        c[i] = B[i * 3] * d[0] + B[i * 3 + 1] * d[1] + B[i * 3 + 2] * d[2];
+    }
+}

@@ -20,6 +20,7 @@
 #include <rocprim/rocprim.hpp>
 #include <cstdint>
 #include "ba_types.h"
+#include "ba_math.h"
 
 // ---------------------------------------------------------------------------------------- structure
 // number of (a <= b) pairs among a landmark's edges whose pose is free
@@ -112,28 +113,19 @@ __global__ __launch_bounds__(256) void k_sp_row_ptr(const unsigned* __restrict__
 
 // ---------------------------------------------------------------------------------------- per LM trial
 // per landmark: Dinv = (Hll + lambda I)^-1, db = Dinv b_l, Y_e = Hpl_e Dinv for its edges
-__device__ __forceinline__ void inv3(const double* m, double* o)
-{
-    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
-    const double id = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
-    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-}
-
-__global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double* __restrict__ Y, double* __restrict__ db)
+__global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= D.L) return;
     double Dm[9], Di[9];
     for (int i = 0; i < 9; i++) Dm[i] = D.Hll[9 * (long long)l + i];
     Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
-    inv3(Dm, Di);
+    ba_inv3(Dm, Di);
     for (int i = 0; i < 9; i++) D.Dinv[9 * (long long)l + i] = Di[i];
     const double b0 = D.bl[3 * (long long)l], b1 = D.bl[3 * (long long)l + 1], b2 = D.bl[3 * (long long)l + 2];
-    db[3 * (long long)l] = Di[0] * b0 + Di[1] * b1 + Di[2] * b2;
-    db[3 * (long long)l + 1] = Di[3] * b0 + Di[4] * b1 + Di[5] * b2;
-    db[3 * (long long)l + 2] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
+    D.db[3 * (long long)l] = Di[0] * b0 + Di[1] * b1 + Di[2] * b2;
+    D.db[3 * (long long)l + 1] = Di[3] * b0 + Di[4] * b1 + Di[5] * b2;
+    D.db[3 * (long long)l + 2] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
 }
 // per edge: Y_e = Hpl_e Dinv(landmark of e)  (one thread per edge: nine times the parallelism of a loop inside k_sp_dinv)
 // Z_e = Hpl_e L^-T  (6 x 3) with Hll + lambda I = L L^T (Cholesky of the landmark's damped 3 x 3 block): Dinv = L^-T L^-1, so
@@ -141,32 +133,18 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda, double*
 // Hpl on the other the kernel gathered from two arrays of 260 MB each at config 5 -- more than the 256 MB MALL holds; one array
 // halves the working set.  (The factor is taken of the block itself, not of its computed inverse: three square roots of pivots that
 // are positive whenever the block is.)
-__global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double lambda, double* __restrict__ Y)
+__global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double lambda)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= D.E) return;
-    const double* H = D.Hll + 9 * (long long)D.edge_point[e];
-    // lower Cholesky factor of H + lambda I (upper half of H read)
-    // Pivots: in exact arithmetic each is >= lambda > 0 (H is a sum of J^T J terms).  For a landmark block that is rank-deficient
-    // (one observation, or no parallax) and a late, tiny lambda the computed second or third pivot can round to <= 0, and its square
-    // root would poison every reduced block the landmark touches.  A pivot below the rounding level of its own diagonal entry is
-    // noise either way, so it is held at that level (2^-52 of the entry): the step stays finite like the reference's, whose 3 x 3
-    // inverse (Eigen's cofactor formula, = inv3 above, used for the back-substitution) does not take square roots.
-    const double d1 = H[4] + lambda, d2 = H[8] + lambda;
-    const double l00 = sqrt(H[0] + lambda), i00 = 1.0 / l00;
-    const double l10 = H[1] * i00, l20 = H[2] * i00;
-    const double l11 = sqrt(fmax(d1 - l10 * l10, 0x1p-52 * d1)), i11 = 1.0 / l11;
-    const double l21 = (H[5] - l20 * l10) * i11;
-    const double i22 = 1.0 / sqrt(fmax(d2 - l20 * l20 - l21 * l21, 0x1p-52 * d2));
+    const int l = D.edge_point[e];
+    double f[6], Bx[18];
+    ba_chol3(D.Hll + 9 * (long long)l, lambda, f);               // (pivot guard: see ba_math.h)
     const double* B = D.Hpl + 18 * (long long)e;
-    double* y = Y + 18 * (long long)e;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {                               // row z of Z solves z L^T = w
-        const double z0 = B[i * 3] * i00;
-        const double z1 = (B[i * 3 + 1] - z0 * l10) * i11;
-        const double z2 = (B[i * 3 + 2] - z0 * l20 - z1 * l21) * i22;
-        y[i * 3] = z0; y[i * 3 + 1] = z1; y[i * 3 + 2] = z2;
-    }
+    for (int i = 0; i < 18; i++) Bx[i] = B[i];
+    const double* d = D.db + 3 * (long long)l;
+    const double dd[3] = { d[0], d[1], d[2] };
+    ba_edge_z_c(Bx, f, dd, D.Z + 18 * (long long)e, D.ce + 6 * (long long)e);
 }
 
 // One workgroup per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Z_a Z_b^T
@@ -254,18 +232,15 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 // one workgroup (4 waves) per free pose: bs = bp - sum over its edges of Hpl_e db(l_e); wave partials added 0..3 (fixed order)
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_sp_bschur(BaDev D, const double* __restrict__ db, double* __restrict__ bs)
+__global__ __launch_bounds__(64 * NW) void k_sp_bschur(BaDev D, double* __restrict__ bs)
 {
     __shared__ double part[NW][6];
     const int f = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (f >= D.nfree) return;
     double c[6] = { 0, 0, 0, 0, 0, 0 };
     for (int k = D.pose_first[f] + threadIdx.x; k < D.pose_first[f + 1]; k += 64 * NW) {
-        const int e = D.pose_edges[k];
-        if (!D.active[e]) continue;
-        const double* B = D.Hpl + 18 * (long long)e;
-        const double* d = db + 3 * (long long)D.edge_point[e];
-        for (int i = 0; i < 6; i++) c[i] += B[i * 3] * d[0] + B[i * 3 + 1] * d[1] + B[i * 3 + 2] * d[2];
+        const double* ce = D.ce + 6 * (long long)D.pose_edges[k];         // Hpl_e db(l_e), left by k_sp_edge_y / the fused linearisation (0 for a dropped edge)
+        for (int i = 0; i < 6; i++) c[i] += ce[i];
     }
     for (int i = 0; i < 6; i++)
         for (int s = 32; s >= 1; s >>= 1) c[i] += __shfl_xor(c[i], s, 64);
@@ -280,17 +255,28 @@ __global__ __launch_bounds__(64 * NW) void k_sp_bschur(BaDev D, const double* __
 }
 
 // one wave per free pose: bs = bp - sum over its edges of Hpl_e db(l_e), fixed order
-__global__ __launch_bounds__(256) void k_sp_bschur_wave(BaDev D, const double* __restrict__ db, double* __restrict__ bs)
+__global__ __launch_bounds__(256) void k_sp_bschur_wave(BaDev D, double* __restrict__ bs)
 {
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (f >= D.nfree) return;
     double c[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int k = D.pose_first[f] + lane; k < D.pose_first[f + 1]; k += 64) {
-        const int e = D.pose_edges[k];
-        if (!D.active[e]) continue;
-        const double* B = D.Hpl + 18 * (long long)e;
-        const double* d = db + 3 * (long long)D.edge_point[e];
-        for (int i = 0; i < 6; i++) c[i] += B[i * 3] * d[0] + B[i * 3 + 1] * d[1] + B[i * 3 + 2] * d[2];
+    // four edges in flight per lane: the 48-byte rows are gathered through the keyframe's edge list
+    const int k1 = D.pose_first[f + 1];
+    for (int k = D.pose_first[f] + lane; k < k1; k += 256) {
+        typedef double bs_d2 __attribute__((ext_vector_type(2)));
+        bs_d2 v[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kk = k + 64 * q;
+#pragma unroll
+            for (int i = 0; i < 3; i++) v[q][i] = bs_d2{0.0, 0.0};
+            if (kk < k1) {
+                const bs_d2* ce = reinterpret_cast<const bs_d2*>(D.ce + 6 * (long long)D.pose_edges[kk]);
+                v[q][0] = ce[0]; v[q][1] = ce[1]; v[q][2] = ce[2];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { c[0] += v[q][0].x; c[1] += v[q][0].y; c[2] += v[q][1].x; c[3] += v[q][1].y; c[4] += v[q][2].x; c[5] += v[q][2].y; }
     }
     for (int i = 0; i < 6; i++)
         for (int s = 32; s >= 1; s >>= 1) c[i] += __shfl_xor(c[i], s, 64);
@@ -1411,10 +1397,10 @@ void sp_launch_row_entries(hipStream_t s, const int* br, const int* bc, int nb, 
 { hipLaunchKernelGGL(k_sp_row_entries, dim3(nblk(nb, 256)), dim3(256), 0, s, br, bc, nb, nfree, key, val); }
 void sp_launch_row_ptr(hipStream_t s, const unsigned* skey, int n_ent, int nfree, int* row_ptr)
 { hipLaunchKernelGGL(k_sp_row_ptr, dim3(nblk(n_ent, 256)), dim3(256), 0, s, skey, n_ent, nfree, row_ptr); }
-void sp_launch_dinv(hipStream_t s, const BaDev& D, double lambda, double* Y, double* db)
+void sp_launch_dinv(hipStream_t s, const BaDev& D, double lambda)
 {
-    if (D.L > 0) hipLaunchKernelGGL(k_sp_dinv, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, lambda, Y, db);
-    if (D.E > 0) hipLaunchKernelGGL(k_sp_edge_y, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, lambda, Y);
+    if (D.L > 0) hipLaunchKernelGGL(k_sp_dinv, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, lambda);
+    if (D.E > 0) hipLaunchKernelGGL(k_sp_edge_y, dim3(nblk(D.E, 256)), dim3(256), 0, s, D, lambda);
 }
 void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, const unsigned long long* pairs, const int* st, const int* en,
                             const int* br, const int* bc, int nb, double* Hb)
@@ -1424,11 +1410,11 @@ void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, cons
     if (nb < 2048) hipLaunchKernelGGL(k_sp_schur_blocks<16>, dim3((nb + 1) / 2), dim3(1024), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
     else hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3((nb + 1) / 2), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
 }
-void sp_launch_bschur(hipStream_t s, const BaDev& D, const double* db, double* bs)
+void sp_launch_bschur(hipStream_t s, const BaDev& D, double* bs)
 {
-    if (D.nfree > 0 && D.nfree < 64) hipLaunchKernelGGL(k_sp_bschur<16>, dim3(D.nfree), dim3(1024), 0, s, D, db, bs);
-    else if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_sp_bschur<4>, dim3(D.nfree), dim3(256), 0, s, D, db, bs);
-    else if (D.nfree > 0) hipLaunchKernelGGL(k_sp_bschur_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, db, bs);
+    if (D.nfree > 0 && D.nfree < 64) hipLaunchKernelGGL(k_sp_bschur<16>, dim3(D.nfree), dim3(1024), 0, s, D, bs);
+    else if (D.nfree > 0 && D.nfree < 512) hipLaunchKernelGGL(k_sp_bschur<4>, dim3(D.nfree), dim3(256), 0, s, D, bs);
+    else if (D.nfree > 0) hipLaunchKernelGGL(k_sp_bschur_wave, dim3(nblk(D.nfree, 4)), dim3(256), 0, s, D, bs);
 }
 void sp_launch_add_lambda(hipStream_t s, const int* diag, int nfree, double lambda, double* Hb)
 { hipLaunchKernelGGL(k_sp_add_lambda, dim3(nblk(6LL * nfree, 256)), dim3(256), 0, s, diag, nfree, lambda, Hb); }

@@ -26,6 +26,8 @@ struct BaDev {
     double* Dinv;                  // [L][9]
     double* Hs; double* bs;        // (6 nfree)^2 row-major, upper block triangle; 6 nfree
     double* x;                     // [6 nfree + 3 L]
+    // per LM trial (ba_sparse.hip): Z = Hpl L^-T per edge (L L^T = Hll + lambda I), db = Dinv b_l per landmark, ce = Hpl db per edge
+    double* Z; double* db; double* ce;
 };
 
 // coarse level of the PCG preconditioner (ba_sparse.hip); Aci == nullptr switches it off

@@ -461,6 +461,20 @@ __device__ __forceinline__ int fc_mbcnt(unsigned long long m, int base)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
 }
+// Diagnostic build only (-DFC_STAMPS, tools/r03_fc_stamps.sh): wave 0 of every workgroup leaves the shader clock at its phase
+// boundaries in a buffer no other code reads; the shipped kernel contains none of this.
+#ifdef FC_STAMPS
+#define FC_STAMP_SLOTS 8
+#define FC_STAMP_WGS (1 << 17)
+__device__ unsigned long long fc_stamps[FC_STAMP_WGS * FC_STAMP_SLOTS];
+#define FC_STAMP(k) do { if (threadIdx.x == 0) { const unsigned wg__ = blockIdx.y * gridDim.x + blockIdx.x; if (wg__ < FC_STAMP_WGS) fc_stamps[wg__ * FC_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+extern "C" int ccm_debug_fc_stamps(unsigned long long* out, int n_wgs)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fc_stamps), (size_t)n_wgs * FC_STAMP_SLOTS * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define FC_STAMP(k) do { } while (0)
+#endif
 template <bool PACKED>
 __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
                                                     unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl, int xcd_on)
@@ -468,6 +482,7 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
     int wx, wy;
     xcd_work_item(xcd_on, wx, wy);
+    FC_STAMP(0);
     const OrbBand B = bands[wx];
     const int f = wy + g.frame0, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const OrbLevel& L = g.lv[B.level];
@@ -552,6 +567,7 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         colmask[tid] = make_uint2(mk[0] | (mk[2] << 16), mk[1] | (mk[3] << 16));
     }
     __syncthreads();
+    FC_STAMP(1);
     if (abl == 1) return;                                    // staging only
     unsigned short* wsurv = surv + wv * WCAP;
     for (int r0 = 3; r0 < bh - 3; r0 += RB) {
@@ -625,6 +641,7 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         if (lane == 0) nsurv[4 + wv] = wcnt;
         __syncthreads();
+        if (r0 == 3) FC_STAMP(5);
         int wfirst[NW + 1];                                    // list index of each wave's first survivor
         wfirst[0] = 0;
 #pragma unroll
@@ -650,7 +667,9 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
         __syncthreads();
+        if (r0 == 3) FC_STAMP(6);
     }
+    FC_STAMP(2);
     // ---- NMS on the list of scored pixels.  With minThFAST <= iniThFAST every stored score is >= minThFAST, so
     // "keep at threshold th" == score >= th and strictly greater than every neighbour inside the cell's rectangle.
     if (abl == 3) return;                                    // no NMS
@@ -685,6 +704,7 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
         }
         __syncthreads();
+        FC_STAMP(3);
         int nk = 0;
         for (int i = 0; i < B.ncells; i++) {
             const int k = cell_k[i];
@@ -714,6 +734,7 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             }
             __syncthreads();
             if (tid < B.ncells) cell_count[(long long)f * g.ncells + B.cell_first + tid] = cell_n[tid];
+            FC_STAMP(4);
             return;
         }
     }

@@ -243,6 +243,16 @@ int ccm_fuse_select(ccm_ctx*, const ccm_frame_grid* kf, const float* scale_facto
                     const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, float th,
                     int chi2_check, int accept_th, int32_t* best_idx, int32_t* best_dist);
 
+/* ccm_fuse_select for n_kf keyframes in ONE launch -- the server's fuse loops call Fuse once per keyframe (src/Mapping.cpp:515-546:
+ * the current keyframe's map points into every neighbour; src/MapMerger.cpp:576-586: the loop map points into every corrected
+ * keyframe).  Map points projected into keyframe k are rows mp_first[k] .. mp_first[k+1]-1 (mp_first[0] = 0) of valid / u / v /
+ * level / mp_desc / best_idx / best_dist; best_idx is an index into keyframe k's own features.  Returns what n_kf sequential
+ * ccm_fuse_select calls return: the selection reads projections, descriptors and features only; a point that an earlier
+ * keyframe's Replace has made bad is skipped by the caller when it applies the results in keyframe order (ORBmatcher.cpp:884-886). */
+int ccm_fuse_select_batch(ccm_ctx*, int n_kf, const ccm_frame_grid* kfs, const float* scale_factors, const float* inv_level_sigma2,
+                          const int32_t* mp_first, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                          const uint8_t* mp_desc, float th, int chi2_check, int accept_th, int32_t* best_idx, int32_t* best_dist);
+
 /* ORBmatcher::SearchBySim3 (ORBmatcher.cpp:1124-1348).  The caller projects every map point of KF1 into KF2 with the
  * Sim3 (valid1/u1/v1/level1 per feature of KF1, :1170-1208; mp_desc1 = GetDescriptor()) and vice versa; both
  * directions select the most similar feature (<= TH_HIGH) and match12[i1] = i2 where they agree (:1330-1345), else -1.

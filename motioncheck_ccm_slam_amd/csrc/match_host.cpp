@@ -282,6 +282,8 @@ struct WinGrid {
 void match_launch_window(hipStream_t, const WinGrid&, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
                          const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn);
 
+void match_launch_window_select_batch(hipStream_t, const WinGrid* grids, const int* q_kf, int nq, const float* qx, const float* qy, const float* qr,
+                                      const int* minl, const int* maxl, const uint8_t* qdesc, const float* inv_sigma2, int accept_th, int* best_idx, int* best_dist);
 void match_launch_window_select(hipStream_t, const WinGrid&, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
                                 const int* maxl, const uint8_t* qdesc, const float* inv_sigma2, int accept_th, int* best_idx, int* best_dist);
 struct GreedyArgs {
@@ -292,7 +294,8 @@ struct GreedyArgs {
 size_t match_window_greedy_lds(int n, int nq);
 int match_launch_window_greedy(hipStream_t, int mode, const GreedyArgs&);
 
-struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn, sel_i, sel_d, is2, act, qlvl, qflag, flag, out, status, qang, fang, ev; };
+struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn, sel_i, sel_d, is2, act, qlvl, qflag, flag, out, status, qang, fang, ev,
+                           grids, qkf; };
 // LDS the single-workgroup acceptance kernel may ask for (claim + flag per feature, one byte per query); larger problems take the
 // host loops below
 static const size_t kGreedyLdsMax = 150 * 1024;
@@ -409,7 +412,7 @@ void match_window_free(WindowBufs* w)
 {
     if (!w) return;
     DevBuf* all[] = { &w->kx, &w->ky, &w->oct, &w->desc, &w->cfirst, &w->citems, &w->qx, &w->qy, &w->qr, &w->minl, &w->maxl, &w->qdesc, &w->ci, &w->cd, &w->cn,
-                      &w->sel_i, &w->sel_d, &w->is2, &w->act, &w->qlvl, &w->qflag, &w->flag, &w->out, &w->status, &w->qang, &w->fang, &w->ev };
+                      &w->sel_i, &w->sel_d, &w->is2, &w->act, &w->qlvl, &w->qflag, &w->flag, &w->out, &w->status, &w->qang, &w->fang, &w->ev, &w->grids, &w->qkf };
     for (DevBuf* b : all) b->release();
     delete w;
 }
@@ -660,6 +663,91 @@ int ccm_fuse_select(ccm_ctx* c, const ccm_frame_grid* kf, const float* scale_fac
     CCM_HIP(c, hipMemcpyAsync(best_dist, W.sel_d.p, (size_t)n_mp * 4, hipMemcpyDeviceToHost, c->stream));
     CCM_HIP(c, hipStreamSynchronize(c->stream));
     for (int m = 0; m < n_mp; m++) if (!valid[m]) { best_idx[m] = -1; best_dist[m] = 256; }
+    return CCM_OK;
+}
+
+// The selection of ccm_fuse_select for n_kf keyframes in one launch: what n_kf sequential calls return (the selection reads the map
+// points' projections and descriptors and the keyframe's features only -- what an earlier keyframe's Replace / AddObservation
+// changes is which points the CALLER still applies, src/ORBmatcher.cpp:884-886, :958-990).  Map points projected into keyframe k are
+// rows mp_first[k] .. mp_first[k + 1] - 1 of valid / u / v / level / mp_desc and of the outputs.
+int ccm_fuse_select_batch(ccm_ctx* c, int n_kf, const ccm_frame_grid* kfs, const float* scale_factors, const float* inv_level_sigma2,
+                          const int32_t* mp_first, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                          const uint8_t* mp_desc, float th, int chi2_check, int accept_th, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c) return CCM_E_ARG;
+    if (n_kf < 0 || (n_kf > 0 && (!kfs || !mp_first))) return ccm_fail(c, CCM_E_ARG, "bad Fuse batch arguments");
+    if (n_kf == 0) return CCM_OK;
+    const int n_mp = mp_first[n_kf];
+    if (mp_first[0] != 0 || n_mp < 0 || (n_mp > 0 && (!valid || !u || !v || !level || !mp_desc || !best_idx || !best_dist || !scale_factors)) ||
+        (chi2_check && !inv_level_sigma2))
+        return ccm_fail(c, CCM_E_ARG, "bad Fuse batch arguments");
+    for (int k = 0; k < n_kf; k++) if (mp_first[k + 1] < mp_first[k] || kfs[k].n < 0) return ccm_fail(c, CCM_E_ARG, "bad Fuse batch arguments");
+    for (int m = 0; m < n_mp; m++) { best_idx[m] = -1; best_dist[m] = 256; }
+    if (n_mp == 0) return CCM_OK;
+    CCM_HIP(c, hipSetDevice(c->device));
+    if (!c->match) c->match = new MatchState();
+    if (!c->match->win) c->match->win = new WindowBufs();
+    WindowBufs& W = *c->match->win;
+    // per keyframe: Frame::AssignFeaturesToGrid (as window_run), everything concatenated; a keyframe's items index its own features
+    std::vector<int> feat_first(n_kf + 1, 0), cell_first_off(n_kf + 1, 0);
+    for (int k = 0; k < n_kf; k++) { feat_first[k + 1] = feat_first[k] + kfs[k].n; cell_first_off[k + 1] = cell_first_off[k] + kfs[k].grid_cols * kfs[k].grid_rows + 1; }
+    const int NF = feat_first[n_kf];
+    std::vector<float> kx(std::max(NF, 1)), ky(std::max(NF, 1)), qr(n_mp);
+    std::vector<int32_t> oct(std::max(NF, 1)), items(std::max(NF, 1)), cfirst(cell_first_off[n_kf]), lo(n_mp), hi(n_mp), qkf(n_mp);
+    std::vector<uint8_t> fdesc((size_t)std::max(NF, 1) * 32);
+    int n_levels = 1;
+    for (int k = 0; k < n_kf; k++) {
+        const ccm_frame_grid& f = kfs[k];
+        const int n = f.n, cells = f.grid_cols * f.grid_rows, f0 = feat_first[k];
+        int* first = cfirst.data() + cell_first_off[k];
+        std::vector<int> cell(n);
+        for (int q = 0; q <= cells; q++) first[q] = 0;
+        for (int i = 0; i < n; i++) {
+            const int px = (int)std::round((f.kp_x[i] - f.min_x) * f.inv_w), py = (int)std::round((f.kp_y[i] - f.min_y) * f.inv_h);
+            cell[i] = (px < 0 || px >= f.grid_cols || py < 0 || py >= f.grid_rows) ? -1 : px * f.grid_rows + py;
+            if (cell[i] >= 0) first[cell[i] + 1]++;
+            kx[f0 + i] = f.kp_x[i]; ky[f0 + i] = f.kp_y[i]; oct[f0 + i] = f.kp_octave[i];
+            n_levels = std::max(n_levels, f.kp_octave[i] + 1);
+        }
+        if (n) memcpy(fdesc.data() + (size_t)f0 * 32, f.desc, (size_t)n * 32);
+        for (int q = 0; q < cells; q++) first[q + 1] += first[q];
+        { std::vector<int> fill(first, first + cells); for (int i = 0; i < n; i++) if (cell[i] >= 0) items[f0 + fill[cell[i]]++] = i; }
+        for (int m = mp_first[k]; m < mp_first[k + 1]; m++) {
+            qkf[m] = k;
+            qr[m] = (valid[m] && n > 0) ? th * scale_factors[level[m]] : -1.f;                    // :909 / :1068
+            lo[m] = level[m] - 1; hi[m] = level[m];                                               // :925-926
+        }
+    }
+    hipStream_t st = c->stream;
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        CCM_RESERVE(c, b, std::max<size_t>(bytes, 16));
+        if (bytes) CCM_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+        return CCM_OK;
+    };
+    int rc;
+    if ((rc = up(W.kx, kx.data(), (size_t)NF * 4)) || (rc = up(W.ky, ky.data(), (size_t)NF * 4)) || (rc = up(W.oct, oct.data(), (size_t)NF * 4)) ||
+        (rc = up(W.desc, fdesc.data(), (size_t)NF * 32)) || (rc = up(W.cfirst, cfirst.data(), cfirst.size() * 4)) || (rc = up(W.citems, items.data(), (size_t)NF * 4)) ||
+        (rc = up(W.qx, u, (size_t)n_mp * 4)) || (rc = up(W.qy, v, (size_t)n_mp * 4)) || (rc = up(W.qr, qr.data(), (size_t)n_mp * 4)) ||
+        (rc = up(W.minl, lo.data(), (size_t)n_mp * 4)) || (rc = up(W.maxl, hi.data(), (size_t)n_mp * 4)) || (rc = up(W.qdesc, mp_desc, (size_t)n_mp * 32)) ||
+        (rc = up(W.qkf, qkf.data(), (size_t)n_mp * 4)))
+        return rc;
+    if (chi2_check && (rc = up(W.is2, inv_level_sigma2, (size_t)n_levels * 4))) return rc;
+    std::vector<WinGrid> grids(n_kf);
+    for (int k = 0; k < n_kf; k++) {
+        const ccm_frame_grid& f = kfs[k];
+        grids[k] = WinGrid{ f.n, f.grid_cols, f.grid_rows, f.min_x, f.min_y, f.inv_w, f.inv_h, W.kx.as<float>() + feat_first[k], W.ky.as<float>() + feat_first[k],
+                            W.oct.as<int>() + feat_first[k], W.desc.as<uint8_t>() + (size_t)feat_first[k] * 32, W.cfirst.as<int>() + cell_first_off[k],
+                            W.citems.as<int>() + feat_first[k] };
+    }
+    if ((rc = up(W.grids, grids.data(), grids.size() * sizeof(WinGrid)))) return rc;
+    CCM_RESERVE(c, W.sel_i, (size_t)n_mp * 4); CCM_RESERVE(c, W.sel_d, (size_t)n_mp * 4);
+    match_launch_window_select_batch(st, W.grids.as<WinGrid>(), W.qkf.as<int>(), n_mp, W.qx.as<float>(), W.qy.as<float>(), W.qr.as<float>(), W.minl.as<int>(),
+                                     W.maxl.as<int>(), W.qdesc.as<uint8_t>(), chi2_check ? W.is2.as<float>() : nullptr, accept_th, W.sel_i.as<int>(), W.sel_d.as<int>());
+    CCM_HIP(c, hipGetLastError());
+    CCM_HIP(c, hipMemcpyAsync(best_idx, W.sel_i.p, (size_t)n_mp * 4, hipMemcpyDeviceToHost, st));
+    CCM_HIP(c, hipMemcpyAsync(best_dist, W.sel_d.p, (size_t)n_mp * 4, hipMemcpyDeviceToHost, st));
+    CCM_HIP(c, hipStreamSynchronize(st));                       // (the staging vectors above stay alive until here)
+    for (int m = 0; m < n_mp; m++) if (!valid[m] || kfs[qkf[m]].n == 0) { best_idx[m] = -1; best_dist[m] = 256; }
     return CCM_OK;
 }
 

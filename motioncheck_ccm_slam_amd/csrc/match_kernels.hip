@@ -522,7 +522,11 @@ __global__ __launch_bounds__(256) void k_window_candidates(WinGrid G, int nq, co
 // SearchBySim3 (:1196-1245): the same window walk as k_window_candidates, but every lane keeps the best (distance, visiting
 // position) of the candidates it filters and the wave reduces to ONE (index, distance) per query.  "First of equal distances
 // wins" (the reference's strict `dist < bestDist` in visiting order) = minimum of distance * 2^32 + position.
-__global__ __launch_bounds__(256) void k_window_select(WinGrid G, int nq, const float* __restrict__ qx, const float* __restrict__ qy,
+// BATCH (ccm_fuse_select_batch): the queries of many keyframes in one launch; query q belongs to keyframe q_kf[q], whose grid is
+// grids[q_kf[q]] (the server's fuse loops call Fuse once per neighbouring keyframe: src/Mapping.cpp:515-546, src/MapMerger.cpp:576-586).
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_window_select(WinGrid G1, const WinGrid* __restrict__ grids, const int* __restrict__ q_kf,
+                                                       int nq, const float* __restrict__ qx, const float* __restrict__ qy,
                                                        const float* __restrict__ qr, const int* __restrict__ min_level,
                                                        const int* __restrict__ max_level, const uint8_t* __restrict__ qdesc,
                                                        const float* __restrict__ inv_sigma2, int accept_th,
@@ -530,6 +534,7 @@ __global__ __launch_bounds__(256) void k_window_select(WinGrid G, int nq, const 
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
+    const WinGrid G = BATCH ? grids[q_kf[q]] : G1;
     const float x = qx[q], y = qy[q], r = qr[q];
     const int minL = min_level[q], maxL = max_level[q];
     unsigned long long best = ~0ull; int bidx = -1;
@@ -582,7 +587,14 @@ __global__ __launch_bounds__(256) void k_window_select(WinGrid G, int nq, const 
 void match_launch_window_select(hipStream_t s, const WinGrid& G, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
                                 const int* maxl, const uint8_t* qdesc, const float* inv_sigma2, int accept_th, int* best_idx, int* best_dist)
 {
-    hipLaunchKernelGGL(k_window_select, dim3((nq + 3) / 4), dim3(256), 0, s, G, nq, qx, qy, qr, minl, maxl, qdesc, inv_sigma2, accept_th, best_idx, best_dist);
+    hipLaunchKernelGGL(k_window_select<false>, dim3((nq + 3) / 4), dim3(256), 0, s, G, (const WinGrid*)nullptr, (const int*)nullptr, nq, qx, qy, qr, minl, maxl, qdesc, inv_sigma2,
+                       accept_th, best_idx, best_dist);
+}
+void match_launch_window_select_batch(hipStream_t s, const WinGrid* grids, const int* q_kf, int nq, const float* qx, const float* qy, const float* qr,
+                                      const int* minl, const int* maxl, const uint8_t* qdesc, const float* inv_sigma2, int accept_th, int* best_idx, int* best_dist)
+{
+    if (nq > 0) hipLaunchKernelGGL(k_window_select<true>, dim3((nq + 3) / 4), dim3(256), 0, s, WinGrid{}, grids, q_kf, nq, qx, qy, qr, minl, maxl, qdesc, inv_sigma2,
+                                   accept_th, best_idx, best_dist);
 }
 
 // k_window_greedy: the ORDER-DEPENDENT acceptance of SearchByProjection(Frame&, vpMapPoints) (ORBmatcher.cpp:71-148, MODE 0),

@@ -181,6 +181,30 @@ def _fuse_select(self, kf: FrameGridView, scale_factors, inv_level_sigma2, valid
 ORBmatcher.FuseSelect = _fuse_select
 
 
+def _fuse_select_batch(self, kfs, scale_factors, inv_level_sigma2, per_kf, th: float, chi2_check: bool, accept_th: int = 50):
+    """FuseSelect for many keyframes in one launch (ccm_fuse_select_batch; the server's fuse loops, src/Mapping.cpp:515-546,
+    src/MapMerger.cpp:576-586).  kfs: list of FrameGridView; per_kf: list of (valid, u, v, level, mp_desc) per keyframe.
+    Returns a list of (best_idx, best_dist) per keyframe -- what FuseSelect returns keyframe by keyframe."""
+    a = np.ascontiguousarray
+    sf = a(scale_factors, "f4"); s2 = a(inv_level_sigma2, "f4")
+    first = np.zeros(len(kfs) + 1, "i4")
+    for k, t in enumerate(per_kf):
+        first[k + 1] = first[k] + len(t[0])
+    cat = lambda i, dt: a(np.concatenate([np.asarray(t[i]) for t in per_kf]) if len(per_kf) else np.zeros(0), dt)
+    va, uu, vv, lv = cat(0, np.uint8), cat(1, "f4"), cat(2, "f4"), cat(3, "i4")
+    md = a(np.concatenate([np.asarray(t[4], np.uint8).reshape(-1, 32) for t in per_kf]) if len(per_kf) else np.zeros((0, 32)), np.uint8)
+    n = int(first[-1])
+    bi = np.full(max(n, 1), -1, "i4"); bd = np.full(max(n, 1), 256, "i4")
+    grids = (_lib.FrameGrid * max(len(kfs), 1))(*[kf.struct() for kf in kfs])
+    p = _lib.ptr
+    self.ctx.check(self.lib.ccm_fuse_select_batch(self.ctx.handle, len(kfs), C.cast(grids, C.c_void_p), p(sf), p(s2), p(first), p(va), p(uu), p(vv), p(lv), p(md),
+                                                  C.c_float(th), int(chi2_check), int(accept_th), p(bi), p(bd)))
+    return [(bi[first[k]:first[k + 1]].copy(), bd[first[k]:first[k + 1]].copy()) for k in range(len(kfs))]
+
+
+ORBmatcher.FuseSelectBatch = _fuse_select_batch
+
+
 def _search_by_sim3(self, kf1: FrameGridView, sf1, kf2: FrameGridView, sf2, valid1, u1, v1, level1, mp_desc1, valid2, u2, v2, level2, mp_desc2,
                     th: float):
     """ORBmatcher::SearchBySim3 (ORBmatcher.cpp:1124-1348) after the caller's projections.  Returns (nFound, match12)."""

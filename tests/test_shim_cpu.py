@@ -120,7 +120,8 @@ def test_every_reference_signature_the_shim_defines_exists_in_the_reference_head
     src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "shim", "*.cpp")))
     for name in ("ORBextractor::operator()", "ORBextractor::ORBextractor", "ORBmatcher::DescriptorDistance", "ORBmatcher::SearchByBoW",
                  "ORBmatcher::SearchByProjection", "Optimizer::MapFusionGBA", "Optimizer::BundleAdjustmentClient",
-                 "Optimizer::GlobalBundleAdjustemntClient", "Optimizer::PoseOptimizationClient", "Optimizer::LocalBundleAdjustmentClient"):
+                 "Optimizer::GlobalBundleAdjustemntClient", "Optimizer::PoseOptimizationClient", "Optimizer::LocalBundleAdjustmentClient",
+                 "ORBmatcher::Fuse(kfptr pKF, const std::vector<mpptr>& vpMapPoints", "ORBmatcher::Fuse(kfptr pKF, cv::Mat Scw"):
         assert name in src, name
 
 

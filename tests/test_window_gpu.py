@@ -131,6 +131,44 @@ def test_fuse_select(ctx, oracle, chi2):
         assert (bi[:900] >= 0).sum() > 400 and (bi[~valid] == -1).all()
 
 
+def test_fuse_select_batch_equals_keyframe_by_keyframe(ctx, oracle):
+    """ccm_fuse_select_batch (round 3): the map points of one keyframe projected into K neighbours, all in one launch, against K
+    sequential calls and against the oracle per keyframe; an empty keyframe and a keyframe without map points ride along."""
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, ctx=ctx)
+    is2 = ex.GetInverseScaleSigmaSquares()
+    rng = np.random.default_rng(21)
+    kfs, per_kf, descs = [], [], []
+    sf = None
+    for k, seed in enumerate((4, 5, 6, 7, 9)):
+        fr, sf, kps, desc = _frame(ctx, seed)
+        n = len(fr.kx)
+        nm = (700, 0, 1500, 300, 40)[k]
+        src = rng.integers(0, n, nm)
+        flips = np.packbits(rng.random((nm, 256)) < 0.05, axis=1, bitorder="little")
+        mp_desc = (desc[src] ^ flips).astype(np.uint8)
+        u = (fr.kx[src] + rng.normal(0, 1.5, nm)).astype("f4"); v = (fr.ky[src] + rng.normal(0, 1.5, nm)).astype("f4")
+        level = np.clip(fr.oct[src] + rng.integers(0, 2, nm), 0, 7).astype("i4")
+        valid = rng.random(nm) < 0.85
+        kfs.append(fr); descs.append(desc); per_kf.append((valid, u, v, level, mp_desc))
+    empty = FrameGridView(np.zeros(0, "f4"), np.zeros(0, "f4"), np.zeros(0, "i4"), np.zeros((0, 32), np.uint8))
+    kfs.insert(2, empty); descs.insert(2, np.zeros((0, 32), np.uint8))
+    per_kf.insert(2, (np.ones(25, bool), rng.uniform(0, 752, 25).astype("f4"), rng.uniform(0, 480, 25).astype("f4"), rng.integers(0, 8, 25).astype("i4"),
+                      rng.integers(0, 256, (25, 32), dtype=np.uint8)))
+    m = ORBmatcher(ctx=ctx)
+    for chi2 in (True, False):
+        got = m.FuseSelectBatch(kfs, sf, is2, per_kf, 3.0, chi2)
+        assert len(got) == len(kfs)
+        for k, (fr, t) in enumerate(zip(kfs, per_kf)):
+            bi, bd = m.FuseSelect(fr, sf, is2, *t, 3.0, chi2)
+            assert (got[k][0] == bi).all() and (got[k][1] == bd).all(), k
+            if len(fr.kx):
+                rbi, rbd = oracle.fuse_select(fr.kx, fr.ky, fr.oct, descs[k], fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, *t, 3.0, chi2)
+                assert (got[k][0] == rbi).all() and (got[k][1] == rbd).all(), k
+            else:
+                assert (got[k][0] == -1).all()
+        assert sum(int((g[0] >= 0).sum()) for g in got) > 800
+
+
 def _noisy_points(fr, desc, rng, n_rel, n_rand, sigma=1.2, flip=0.04):
     """Map points = features of frame `fr` re-projected with noise (+ unrelated ones): desc, u, v, level."""
     n = len(fr.kx)

@@ -76,6 +76,20 @@ is2 = ex.GetInverseScaleSigmaSquares()
 t_gpu = timed(lambda: m.FuseSelect(fr, sf, is2, valid, px, py, lvl, mp_desc, 3.0, True))
 t_cpu = timed(lambda: O.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, valid, px, py, lvl, mp_desc, 3.0, True), 2)
 out["F1_fuse_select_20k"] = {"map_points": nmp, "gpu_ms": round(t_gpu * 1e3, 3), "cpu_oracle_ms": round(t_cpu * 1e3, 1), "acceptance": "device (k_window_select)"}
+# the server's fuse loop (src/Mapping.cpp:515-546): one keyframe's 1000 map points into 20 neighbours -- keyframe by keyframe and
+# in one launch (ccm_fuse_select_batch, round 3)
+K, nm = 20, 1000
+kfs = [fr] * K
+per_kf = []
+for k in range(K):
+    s2 = rng.integers(0, n, nm)
+    per_kf.append((np.ones(nm, np.uint8), (fr.kx[s2] + rng.normal(0, 2.0, nm)).astype("f4"), (fr.ky[s2] + rng.normal(0, 2.0, nm)).astype("f4"),
+                   np.clip(fr.oct[s2] + rng.integers(0, 2, nm), 0, 7).astype("i4"), desc[s2] ^ np.packbits(rng.random((nm, 256)) < 0.05, axis=1, bitorder="little")))
+t_seq = timed(lambda: [m.FuseSelect(kfs[k], sf, is2, *per_kf[k], 3.0, True) for k in range(K)])
+t_bat = timed(lambda: m.FuseSelectBatch(kfs, sf, is2, per_kf, 3.0, True))
+t_cpu = timed(lambda: [O.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, *per_kf[k], 3.0, True) for k in range(K)], 2)
+out["F1_fuse_select_20_keyframes"] = {"keyframes": K, "map_points_per_keyframe": nm, "sequential_calls_ms": round(t_seq * 1e3, 3), "one_batched_call_ms": round(t_bat * 1e3, 3),
+                                      "cpu_oracle_ms": round(t_cpu * 1e3, 1)}
 t_gpu = timed(lambda: m.SearchByProjectionSim3(fr, sf, valid, px, py, lvl, mp_desc, observed, matched, 8.0))
 t_cpu = timed(lambda: O.search_by_projection_sim3(fr, sf, valid, px, py, lvl, mp_desc, observed, matched, 8.0), 2)
 os.environ["CCM_WINDOW_HOST_ACCEPT"] = "1"      # read once per process by the library: the host-acceptance figure comes from a child process

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 // Survivors are appended per wave to the wave's own segment of the list (running count in a scalar register, no
 // atomic): a row block has at most surv_cap / 4 items of 4 pixels, a wave takes every (FC_TPB / 64)-th run of 64
 // items, so its segment never needs more than this many entries.
-__host__ __device__ inline int fc_wave_cap(int surv_cap) { return ((surv_cap / 4 + FC_TPB - 1) / FC_TPB) * 256; }
+__host__ __device__ inline int fc_wave_cap(int surv_cap) { (void)surv_cap; return 320; }      // wave-local stack: at most 63 waiting + the 256 pixels of one item
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {
     return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 16 + 64 * 8;
@@ -555,9 +555,7 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const OrbCell cfirst = cells[B.cell_first], clast = cells[B.cell_first + B.ncells - 1];
     const int c_lo = cfirst.x0 + 3 - B.xa, c_hi = clast.x0 + clast.cw - 3 - B.xa;
     const int t_lo = min(g.ini_th, g.min_th);
-    // rows per block: at most FC_SURV pixels, the detection rows dealt evenly to the blocks
-    const int rb_max = max(1, FC_SURV / P), n_rblk = (bh - 6 + rb_max - 1) / rb_max;
-    const int RB = n_rblk > 0 ? (bh - 6 + n_rblk - 1) / n_rblk : 1;
+    (void)FC_SURV;                                           // (rounds 1-2: rows per block of the pooled survivor list)
     // dwords that hold at least one detection column and have both neighbours inside the row
     const int dw_lo = max(1, c_lo >> 2);
     const int dw_hi = min(PW - 2, (c_hi - 1) >> 2);
@@ -570,12 +568,32 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     FC_STAMP(1);
     if (abl == 1) return;                                    // staging only
     unsigned short* wsurv = surv + wv * WCAP;
-    for (int r0 = 3; r0 < bh - 3; r0 += RB) {
-        int wcnt = 0;                                          // survivors this wave has appended (wave-uniform)
-        const int r1 = min(r0 + RB, bh - 3);
-        const int items = (r1 - r0) * PW;
-        for (int it0 = 0; it0 < items; it0 += FC_TPB) {           // uniform trip count: the ballots below need whole waves
-            const int it = it0 + tid;
+    // ---- rejection + scoring, WAVE-LOCAL (round 3): a wave tests its own runs of 64 items (4 pixels per lane), pushes the survivors on
+    // its own stack in LDS, and scores them 64 at a time -- a full wave per 130-instruction score -- as soon as 64 are waiting.  No
+    // workgroup barrier until every pixel of the band is scored: round 2 pooled the survivors of a row block over the four waves
+    // (two barriers per row block, and every wave waited for the slowest at each of them).  The stack never holds more than
+    // 63 + 256 entries.  The order in which pixels are scored does not matter: the NMS below works on the set.
+    auto score_at = [&](int pos) {
+        const uint8_t* c = T + pos;
+        const int v = c[0];
+        int r[16];
+        r[0] = c[3 * P];      r[1] = c[3 * P + 1];  r[2] = c[2 * P + 2];  r[3] = c[P + 3];
+        r[4] = c[3];          r[5] = c[-P + 3];     r[6] = c[-2 * P + 2]; r[7] = c[-3 * P + 1];
+        r[8] = c[-3 * P];     r[9] = c[-3 * P - 1]; r[10] = c[-2 * P - 2]; r[11] = c[-P - 3];
+        r[12] = c[-3];        r[13] = c[P - 3];     r[14] = c[2 * P - 2]; r[15] = c[3 * P - 1];
+        const int sc = fast_score16(v, r);
+        if (sc >= t_lo && sc > 0) {
+            S[pos] = (uint8_t)sc;
+            const int q = atomicAdd(nsurv + 1, 1);
+            if (q < FC_NZ) nz[q] = (unsigned short)pos;
+        }
+    };
+    {
+        int wcnt = 0;                                          // entries on this wave's stack (wave-uniform)
+        const int items = (bh - 6) * PW;
+        constexpr int r0 = 3;
+        for (int it0 = wv * 64; it0 < items; it0 += FC_TPB) {
+            const int it = it0 + lane;
             const int rr = (int)(((unsigned)it * pw_inv) >> 20);
             const int row = r0 + rr, dw = it - rr * PW;
             const int px = 4 * dw;
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const bool k2 = PACKED ? (kk0 >> 16) != 0u : (keep4 & 4u) != 0u, k3 = PACKED ? (kk1 >> 16) != 0u : (keep4 & 8u) != 0u;
             const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
             if ((m0 | m1 | m2 | m3) != 0ull) {
-                // rank of the lane's pixel i among the wave's survivors of this item: pixels 0 of all lanes first, then
+                // stack slot of the lane's pixel i among the wave's survivors of this item: pixels 0 of all lanes first, then
                 // pixels 1, ...; v_mbcnt adds the count of lower lanes to the running base
                 const int b1 = wcnt + __popcll(m0), b2 = b1 + __popcll(m1), b3 = b2 + __popcll(m2);
                 const int pos0 = r0 * P + 4 * it;                  // == row * P + px, as P == 4 * PW
@@ -637,38 +655,15 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 if (k2) wsurv[fc_mbcnt(m2, b2)] = (unsigned short)(pos0 + 2);
                 if (k3) wsurv[fc_mbcnt(m3, b3)] = (unsigned short)(pos0 + 3);
                 wcnt = b3 + __popcll(m3);
+                // the LDS operations of one wave complete in order; the fence keeps the compiler from moving the pops above the pushes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                while (wcnt >= 64 && abl != 2) { wcnt -= 64; score_at(wsurv[wcnt + lane]); }
+                if (abl == 2) wcnt = 0;                            // ablation: no scoring
             }
         }
-        if (lane == 0) nsurv[4 + wv] = wcnt;
-        __syncthreads();
-        if (r0 == 3) FC_STAMP(5);
-        int wfirst[NW + 1];                                    // list index of each wave's first survivor
-        wfirst[0] = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) wfirst[w + 1] = wfirst[w] + nsurv[4 + w];
-        const int ns = abl == 2 ? 0 : wfirst[NW];              // abl 2: no scoring
-        for (int si = tid; si < ns; si += FC_TPB) {
-            int w = 0, j = si;
-#pragma unroll
-            for (int k = 1; k < NW; k++) if (si >= wfirst[k]) { w = k; j = si - wfirst[k]; }
-            const int pos = surv[w * WCAP + j];
-            const uint8_t* c = T + pos;
-            const int v = c[0];
-            int r[16];
-            r[0] = c[3 * P];      r[1] = c[3 * P + 1];  r[2] = c[2 * P + 2];  r[3] = c[P + 3];
-            r[4] = c[3];          r[5] = c[-P + 3];     r[6] = c[-2 * P + 2]; r[7] = c[-3 * P + 1];
-            r[8] = c[-3 * P];     r[9] = c[-3 * P - 1]; r[10] = c[-2 * P - 2]; r[11] = c[-P - 3];
-            r[12] = c[-3];        r[13] = c[P - 3];     r[14] = c[2 * P - 2]; r[15] = c[3 * P - 1];
-            const int sc = fast_score16(v, r);
-            if (sc >= t_lo && sc > 0) {
-                S[pos] = (uint8_t)sc;
-                const int q = atomicAdd(nsurv + 1, 1);
-                if (q < FC_NZ) nz[q] = (unsigned short)pos;
-            }
-        }
-        __syncthreads();
-        if (r0 == 3) FC_STAMP(6);
+        if (lane < wcnt && abl != 2) score_at(wsurv[lane]);
     }
+    __syncthreads();
     FC_STAMP(2);
     // ---- NMS on the list of scored pixels.  With minThFAST <= iniThFAST every stored score is >= minThFAST, so
     // "keep at threshold th" == score >= th and strictly greater than every neighbour inside the cell's rectangle.

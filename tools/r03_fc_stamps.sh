@@ -22,9 +22,9 @@ assert lib.ccm_debug_fc_stamps(buf.ctypes.data, n) == 0
 ok = buf[:, 4] > 0
 b = buf[ok].astype(np.int64)
 print("workgroups with stamps:", int(ok.sum()))
-names = ["start -> staged (barrier 1)", "staged -> first rejection pass done", "first rejection -> first scoring done", "first scoring done -> all row blocks done",
-         "row blocks done -> local maxima listed", "local maxima -> written (end)"]
-seq = [(0, 1), (1, 5), (5, 6), (6, 2), (2, 3), (3, 4)]
+names = ["start -> staged (barrier 1)", "staged -> every pixel scored (wave-local rejection + scoring, barrier 2)",
+         "scored -> local maxima listed", "local maxima -> written (end)"]
+seq = [(0, 1), (1, 2), (2, 3), (3, 4)]
 tot = (b[:, 4] - b[:, 0])
 print("s_memtime ticks (100 MHz constant clock? or shader clock): total median %.0f  mean %.0f" % (np.median(tot), tot.mean()))
 for nm, (a, c) in zip(names, seq):

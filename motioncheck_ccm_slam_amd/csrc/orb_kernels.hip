@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 __host__ __device__ inline int fc_wave_cap(int surv_cap) { (void)surv_cap; return 320; }      // wave-local stack: at most 63 waiting + the 256 pixels of one item
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {
-    return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 16 + 64 * 8;
+    return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 16 + 64 * 8 + FC_CELLS * 12 + 256;
 }
 
 
@@ -484,6 +484,10 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     xcd_work_item(xcd_on, wx, wy);
     FC_STAMP(0);
     const OrbBand B = bands[wx];
+#ifdef FC_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (diagnostic: the band descriptor has arrived)
+#endif
+    FC_STAMP(6);
     const int f = wy + g.frame0, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const OrbLevel& L = g.lv[B.level];
     const int P = B.pitch, bh = B.bh, PW = P >> 2;
@@ -501,11 +505,20 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     short* clo = reinterpret_cast<short*>(cell_k + FC_CELLS); // per cell: first detection column of the tile, and its width
     short* cwd = clo + FC_CELLS;
     uint2* colmask = reinterpret_cast<uint2*>(cwd + FC_CELLS);       // per tile dword: 16-bit lane masks of its detection columns: .x pixels 0 and 2, .y pixels 1 and 3
+    // what the NMS needs of a cell, staged once (a global load of the cell record sat on the NMS's critical path): first slot and slot
+    // count of its candidate list, the image coordinates of its detection rectangle's origin; and the cell of every tile column
+    int* cslot = reinterpret_cast<int*>(colmask + 64);
+    int* ccap = cslot + FC_CELLS;
+    short* cox = reinterpret_cast<short*>(ccap + FC_CELLS);
+    short* coy = cox + FC_CELLS;
+    uint8_t* colcell = reinterpret_cast<uint8_t*>(coy + FC_CELLS);   // [256] 255 = no cell's detection column
     if (tid < FC_CELLS) {
         cell_hi[tid] = 0; cell_n[tid] = 0; cell_k[tid] = 0;
         if (tid < B.ncells) {
             const OrbCell c = cells[B.cell_first + tid];
             clo[tid] = (short)(c.x0 + 3 - B.xa); cwd[tid] = (short)(c.cw - 6);
+            cslot[tid] = c.slot_first; ccap[tid] = c.slot_cap;
+            cox[tid] = (short)(c.x0 + 3 - ORB_BORDER); coy[tid] = (short)(c.y0 + 3 - ORB_BORDER);
         }
     }
     if (tid == 0) { nsurv[1] = 0; nsurv[2] = 0; }
@@ -551,6 +564,10 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             S[i] = 0;
         }
     }
+#ifdef FC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (diagnostic: this wave's pixels have arrived)
+#endif
+    FC_STAMP(7);
     // columns of the tile that belong to some cell's detection area: [c_lo, c_hi)
     const OrbCell cfirst = cells[B.cell_first], clast = cells[B.cell_first + B.ncells - 1];
     const int c_lo = cfirst.x0 + 3 - B.xa, c_hi = clast.x0 + clast.cw - 3 - B.xa;
@@ -564,9 +581,15 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         for (int i = 0; i < 4; i++) mk[i] = (4 * tid + i >= c_lo && 4 * tid + i < c_hi) ? 0xFFFFu : 0u;
         colmask[tid] = make_uint2(mk[0] | (mk[2] << 16), mk[1] | (mk[3] << 16));
     }
+    FC_STAMP(5);                                             // (diagnostic: wave 0's own staging is issued; the barrier below waits for its data and the other waves)
     __syncthreads();
     FC_STAMP(1);
     if (abl == 1) return;                                    // staging only
+    if (tid < P) {                                           // (read after the next barrier)
+        int ci = 255;
+        for (int i = 0; i < B.ncells && i < FC_CELLS; i++) if (tid >= clo[i] && tid < clo[i] + cwd[i]) ci = i;
+        colcell[tid] = (uint8_t)ci;
+    }
     unsigned short* wsurv = surv + wv * WCAP;
     // ---- rejection + scoring, WAVE-LOCAL (round 3): a wave tests its own runs of 64 items (4 pixels per lane), pushes the survivors on
     // its own stack in LDS, and scores them 64 at a time -- a full wave per 130-instruction score -- as soon as 64 are waiting.  No
@@ -679,10 +702,8 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         for (int e = tid; e < nnz; e += FC_TPB) {
             const int pos = nz[e];
             const int row = (int)__umulhi((unsigned)pos, p_inv), col = pos - row * P;
-            int ci = -1;
-            for (int i = 0; i < B.ncells; i++)
-                if (col >= clo[i] && col < clo[i] + cwd[i]) ci = i;
-            if (ci < 0) continue;
+            const int ci = colcell[col];
+            if (ci == 255) continue;
             const int xx = col - clo[ci], yy = row - 3, rw = cwd[ci];
             const uint8_t* p = S + pos;
             const int sc = p[0];
@@ -720,15 +741,20 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     const unsigned o = bucket[k];
                     rank += ((o & 255u) >= th && (o >> 8) < (me >> 8)) ? 1 : 0;
                 }
-                const OrbCell c = cells[B.cell_first + ci];
-                if (rank < c.slot_cap)
-                    slots[(long long)f * g.slots_per_frame + c.slot_first + rank] =
-                        ((me & 255u) << 24) | ((unsigned)(c.y0 + 3 - ORB_BORDER + (int)((me >> 14) & 63u)) << 12) |
-                        (unsigned)(c.x0 + 3 - ORB_BORDER + (int)((me >> 8) & 63u));
-                atomicAdd(cell_n + ci, 1);
+                if (rank < ccap[ci])
+                    slots[(long long)f * g.slots_per_frame + cslot[ci] + rank] =
+                        ((me & 255u) << 24) | ((unsigned)(coy[ci] + (int)((me >> 14) & 63u)) << 12) | (unsigned)(cox[ci] + (int)((me >> 8) & 63u));
             }
-            __syncthreads();
-            if (tid < B.ncells) cell_count[(long long)f * g.ncells + B.cell_first + tid] = cell_n[tid];
+            // a cell's count = its local maxima at the chosen threshold: one thread per cell counts its bucket (an atomic per keypoint
+            // and a barrier before the store, until round 3)
+            if (tid >= FC_TPB - FC_CELLS && FC_TPB - 1 - tid < B.ncells) {
+                const int ci = FC_TPB - 1 - tid;
+                const unsigned th = (unsigned)(cell_hi[ci] > 0 ? g.ini_th : g.min_th);
+                const unsigned* bucket = kept + ci * cap_c;
+                int cnt = 0;
+                for (int k = 0; k < cell_k[ci]; k++) cnt += (bucket[k] & 255u) >= th ? 1 : 0;
+                cell_count[(long long)f * g.ncells + B.cell_first + ci] = cnt;
+            }
             FC_STAMP(4);
             return;
         }

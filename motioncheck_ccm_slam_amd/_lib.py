@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccm_hot.so")
+# CCM_HOT_LIB: another build of the same ABI (A/B timing of kernel variants, tools/ab_orb.sh); the ABI version is checked either way
+LIB_PATH = os.environ.get("CCM_HOT_LIB") or os.path.join(_HERE, "libccm_hot.so")
 
 CCM_OK = 0
 ERRORS = {-1: "CCM_E_ARG", -2: "CCM_E_DEVICE", -3: "CCM_E_NOMEM", -4: "CCM_E_CAPACITY",

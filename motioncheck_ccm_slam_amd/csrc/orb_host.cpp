@@ -227,12 +227,25 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
         int pitch = 0;
         while (b < S.cells.size() && S.cells[b].level == c0.level && S.cells[b].y0 == c0.y0) {
             const int p2 = (int)align_up((size_t)(S.cells[b].x0 + S.cells[b].cw + 4 - xa), 16);   // 16: the tile is staged 16 bytes per lane
-            if (b > a && p2 > pcap) break;
+            if (b > a && (p2 > pcap || b - a >= ORB_BAND_CELLS)) break;                             // (the band record carries its cells: at most ORB_BAND_CELLS)
             pitch = p2; b++;
         }
         OrbBand band{};
-        band.cell_first = (int)a; band.ncells = (int)(b - a); band.level = c0.level; band.xa = (short)xa; band.y0 = c0.y0;
-        band.pitch = (short)pitch; band.bh = c0.ch;
+        band.cell_first = (int)a; band.ncells = (int)(b - a); band.level = c0.level; band.xa = (short)xa; band.y0 = (short)c0.y0;
+        band.pitch = (short)pitch; band.bh = (short)c0.ch;
+        {
+            const OrbCell& cl = S.cells[b - 1];
+            const int PW = pitch / 4, PQ = std::max(pitch / 16, 1);
+            band.c_lo = (short)(c0.x0 + 3 - xa); band.c_hi = (short)(cl.x0 + cl.cw - 3 - xa);
+            band.dw_lo = (short)std::max(1, band.c_lo >> 2); band.dw_hi = (short)std::min(PW - 2, (band.c_hi - 1) >> 2);
+            band.pw_inv = (1u << 20) / (unsigned)PW + 1u; band.pq_inv = (1u << 20) / (unsigned)PQ + 1u;
+            band.w = G.lv[c0.level].w; band.h = G.lv[c0.level].h;
+            for (size_t k = a; k < b; k++) {
+                const OrbCell& ck = S.cells[k];
+                band.clo[k - a] = (short)(ck.x0 + 3 - xa); band.cwd[k - a] = (short)(ck.cw - 6);
+                band.slot_first[k - a] = ck.slot_first; band.slot_cap[k - a] = ck.slot_cap;
+            }
+        }
         for (size_t k = a; k < b; k++) if (S.cells[k].ch != c0.ch) S.fused = false;      // cannot happen: one row, one height
         S.surv_cap = std::max(S.surv_cap, pitch);                 // at least one row per block
         S.bands.push_back(band);
@@ -285,6 +298,10 @@ static int orb_prepare(ccm_ctx* c, const ccm_orb_params* p, int w, int h, int nf
     if (!tab_s.empty()) CCM_HIP(c, hipMemcpyAsync(tb + s_base, tab_s.data(), tab_s.size() * 2, hipMemcpyHostToDevice, c->stream));
     if (!S.cells.empty())
         CCM_HIP(c, hipMemcpyAsync(S.cells_dev.p, S.cells.data(), S.cells.size() * sizeof(OrbCell), hipMemcpyHostToDevice, c->stream));
+    for (OrbBand& b : S.bands) {                       // the level images' device addresses are known now
+        const OrbLevel& L = G.lv[b.level];
+        b.img = b.level > 0 ? L.img : nullptr; b.plane = L.plane; b.lpitch = L.pitch;
+    }
     if (!S.bands.empty())
         CCM_HIP(c, hipMemcpyAsync(S.bands_dev.p, S.bands.data(), S.bands.size() * sizeof(OrbBand), hipMemcpyHostToDevice, c->stream));
     CCM_HIP(c, hipStreamSynchronize(c->stream));     // the host vectors above go out of scope

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 __host__ __device__ inline int fc_wave_cap(int surv_cap) { (void)surv_cap; return 320; }      // wave-local stack: at most 63 waiting + the 256 pixels of one item
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {
-    return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 16 + 64 * 8 + FC_CELLS * 12 + 256;
+    return 2 * (size_t)pitch * bh + (size_t)fc_wave_cap(surv_cap) * (FC_TPB / 64) * 2 + 32 + FC_NZ * 2 + FC_KEPT * 4 + FC_CELLS * 16 + 64 * 8 + 256 + 64;
 }
 
 
@@ -475,9 +475,12 @@ extern "C" int ccm_debug_fc_stamps(unsigned long long* out, int n_wgs)
 #else
 #define FC_STAMP(k) do { } while (0)
 #endif
+// element ci (per lane) of four wave-uniform values: three selects, no memory
+template <class T>
+__device__ __forceinline__ int sel4(int ci, const T (&a)[4]) { return ci == 0 ? (int)a[0] : ci == 1 ? (int)a[1] : ci == 2 ? (int)a[2] : (int)a[3]; }
 template <bool PACKED>
 __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_cells(const OrbGeom g, const OrbCell* __restrict__ cells, const OrbBand* __restrict__ bands,
-                                                    unsigned* __restrict__ slots, int* __restrict__ cell_count, int FC_SURV, int abl, int xcd_on)
+                                                    unsigned* __restrict__ slots, int* __restrict__ cell_count, int unused_, int abl, int xcd_on)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fc_smem[];
     int wx, wy;
@@ -488,13 +491,28 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (diagnostic: the band descriptor has arrived)
 #endif
     FC_STAMP(6);
+    // the band's cells, held in scalar registers from here on (left to itself the compiler loads them again where the NMS uses them:
+    // another scalar-load latency in each of its two passes, +1,400 cycles per band measured)
+    int bclo[4], bcwd[4], bsfirst[4], bscap[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        bclo[i] = B.clo[i]; bcwd[i] = B.cwd[i]; bsfirst[i] = B.slot_first[i]; bscap[i] = B.slot_cap[i];
+        asm volatile("" : "+s"(bclo[i]), "+s"(bcwd[i]), "+s"(bsfirst[i]), "+s"(bscap[i]));
+    }
+    int bxa = B.xa, by0 = B.y0, bncells = B.ncells, bcfirst = B.cell_first;
+    asm volatile("" : "+s"(bxa), "+s"(by0), "+s"(bncells), "+s"(bcfirst));
     const int f = wy + g.frame0, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const OrbLevel& L = g.lv[B.level];
+    // the level's image: from the band record, except level 0 (the caller's frames: pointer, pitch and plane are per call and sit at a
+    // fixed place of the kernel arguments -- no load that depends on the band record)
+    const bool lvl0 = B.level == 0;
+    const uint8_t* const Limg = lvl0 ? g.lv[0].img : B.img;
+    const long long Lplane = lvl0 ? g.lv[0].plane : B.plane;
+    const int Lpitch = lvl0 ? g.lv[0].pitch : B.lpitch, Lw = B.w, Lh = B.h;
     const int P = B.pitch, bh = B.bh, PW = P >> 2;
     uint8_t* T = fc_smem;                                   // pixels  [bh][P]
     uint8_t* S = fc_smem + (size_t)P * bh;                  // scores  [bh][P]
     constexpr int NW = FC_TPB / 64;
-    const int WCAP = fc_wave_cap(FC_SURV);
+    const int WCAP = fc_wave_cap(0);
     unsigned short* surv = reinterpret_cast<unsigned short*>(S + (size_t)P * bh);     // [NW][WCAP]
     int* nsurv = reinterpret_cast<int*>(surv + NW * WCAP);   // [1] scored pixels, [2] local maxima, [4 + w] survivors of wave w in the row block
     unsigned short* nz = reinterpret_cast<unsigned short*>(nsurv + 8);
@@ -502,41 +520,34 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     int* cell_hi = reinterpret_cast<int*>(kept + FC_KEPT);   // per cell: local maxima with score >= iniThFAST
     int* cell_n = cell_hi + FC_CELLS;                        // per cell: keypoints written
     int* cell_k = cell_n + FC_CELLS;                         // per cell: local maxima in the cell's bucket of `kept`
-    short* clo = reinterpret_cast<short*>(cell_k + FC_CELLS); // per cell: first detection column of the tile, and its width
-    short* cwd = clo + FC_CELLS;
-    uint2* colmask = reinterpret_cast<uint2*>(cwd + FC_CELLS);       // per tile dword: 16-bit lane masks of its detection columns: .x pixels 0 and 2, .y pixels 1 and 3
-    // what the NMS needs of a cell, staged once (a global load of the cell record sat on the NMS's critical path): first slot and slot
-    // count of its candidate list, the image coordinates of its detection rectangle's origin; and the cell of every tile column
-    int* cslot = reinterpret_cast<int*>(colmask + 64);
-    int* ccap = cslot + FC_CELLS;
-    short* cox = reinterpret_cast<short*>(ccap + FC_CELLS);
-    short* coy = cox + FC_CELLS;
-    uint8_t* colcell = reinterpret_cast<uint8_t*>(coy + FC_CELLS);   // [256] 255 = no cell's detection column
-    if (tid < FC_CELLS) {
-        cell_hi[tid] = 0; cell_n[tid] = 0; cell_k[tid] = 0;
-        if (tid < B.ncells) {
-            const OrbCell c = cells[B.cell_first + tid];
-            clo[tid] = (short)(c.x0 + 3 - B.xa); cwd[tid] = (short)(c.cw - 6);
-            cslot[tid] = c.slot_first; ccap[tid] = c.slot_cap;
-            cox[tid] = (short)(c.x0 + 3 - ORB_BORDER); coy[tid] = (short)(c.y0 + 3 - ORB_BORDER);
-        }
-    }
+    uint2* colmask = reinterpret_cast<uint2*>(cell_k + FC_CELLS + FC_CELLS);     // per tile dword: 16-bit lane masks of its detection columns: .x pixels 0 and 2, .y pixels 1 and 3
+    // (what the NMS needs of a cell -- its detection columns and its candidate slots -- comes with the band record: until round 3 the
+    //  cell records were loaded from global memory, first on the NMS's critical path, then in front of the pixel loads)
+    uint8_t* colcell = reinterpret_cast<uint8_t*>(colmask + 64);     // [256] cell of a tile column; 255 = no cell's detection column
+    if (tid < FC_CELLS) { cell_hi[tid] = 0; cell_n[tid] = 0; cell_k[tid] = 0; }
+    // per cell, for the NMS (indexed per lane there: an LDS read measured 0.7 % faster than three selects on the scalar registers)
+    int* l_clo = reinterpret_cast<int*>(colcell + 256); int* l_cwd = l_clo + 4; int* l_sfirst = l_cwd + 4; int* l_scap = l_sfirst + 4;
+    if (tid < 4) { l_clo[tid] = sel4(tid, bclo); l_cwd[tid] = sel4(tid, bcwd); l_sfirst[tid] = sel4(tid, bsfirst); l_scap[tid] = sel4(tid, bscap); }
     if (tid == 0) { nsurv[1] = 0; nsurv[2] = 0; }
-    const uint8_t* img = L.img + (long long)f * L.plane;
+    const uint8_t* img = Limg + (long long)f * Lplane;
     // ---- stage pixels (clamped: duplicates are only read for pixels whose score is not needed), zero the scores
-    const bool dword_ok = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)L.pitch) & 3) == 0 && L.pitch >= ((L.w + 3) & ~3);
+    const bool dword_ok = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)Lpitch) & 3) == 0 && Lpitch >= ((Lw + 3) & ~3);
     // i / PW by multiply-shift: exact for i < 2^20 / PW (i <= 65 * 64 here)
-    const unsigned pw_inv = (1u << 20) / (unsigned)PW + 1u;
+    const unsigned pw_inv = B.pw_inv;
+#ifdef FC_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (diagnostic: level record and everything scalar before the pixel loads has arrived)
+#endif
+    FC_STAMP(5);
     if (dword_ok && (P & 15) == 0) {
         // 16 bytes per lane: one global load and two ds_write_b128 (pixels, zeroed scores) per 16 pixels; the last
         // chunks of a row are clamped dword by dword
-        const int wmax = ((L.w - 1) & ~3);
+        const int wmax = ((Lw - 1) & ~3);
         const int PQ = P >> 4;
-        const unsigned pq_inv = (1u << 20) / (unsigned)PQ + 1u;   // i / PQ exact for i < 2^20 / PQ
+        const unsigned pq_inv = B.pq_inv;                          // i / PQ exact for i < 2^20 / PQ
         for (int i = tid; i < bh * PQ; i += FC_TPB) {
             const int ly = (int)(((unsigned)i * pq_inv) >> 20), lq = i - ly * PQ;
-            const int gy = min(B.y0 + ly, L.h - 1), gx = B.xa + 16 * lq;
-            const uint8_t* rowp = img + (long long)gy * L.pitch;
+            const int gy = min(B.y0 + ly, Lh - 1), gx = B.xa + 16 * lq;
+            const uint8_t* rowp = img + (long long)gy * Lpitch;
             uint4 v;
             if (gx + 12 <= wmax) __builtin_memcpy(&v, rowp + gx, 16);
             else {
@@ -549,18 +560,18 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             reinterpret_cast<uint4*>(S)[i] = make_uint4(0u, 0u, 0u, 0u);
         }
     } else if (dword_ok) {
-        const int wmax = ((L.w - 1) & ~3);
+        const int wmax = ((Lw - 1) & ~3);
         for (int i = tid; i < bh * PW; i += FC_TPB) {
             const int ly = (int)(((unsigned)i * pw_inv) >> 20), lx = i - ly * PW;
-            const int gy = min(B.y0 + ly, L.h - 1), gx = min(B.xa + 4 * lx, wmax);
-            reinterpret_cast<unsigned*>(T)[i] = *reinterpret_cast<const unsigned*>(img + (long long)gy * L.pitch + gx);
+            const int gy = min(B.y0 + ly, Lh - 1), gx = min(B.xa + 4 * lx, wmax);
+            reinterpret_cast<unsigned*>(T)[i] = *reinterpret_cast<const unsigned*>(img + (long long)gy * Lpitch + gx);
             reinterpret_cast<unsigned*>(S)[i] = 0u;
         }
     } else {
         for (int i = tid; i < bh * P; i += FC_TPB) {
             const int ly = i / P, lx = i - ly * P;
-            const int gy = min(B.y0 + ly, L.h - 1), gx = min(B.xa + lx, L.w - 1);
-            T[i] = img[(long long)gy * L.pitch + gx];
+            const int gy = min(B.y0 + ly, Lh - 1), gx = min(B.xa + lx, Lw - 1);
+            T[i] = img[(long long)gy * Lpitch + gx];
             S[i] = 0;
         }
     }
@@ -569,25 +580,22 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #endif
     FC_STAMP(7);
     // columns of the tile that belong to some cell's detection area: [c_lo, c_hi)
-    const OrbCell cfirst = cells[B.cell_first], clast = cells[B.cell_first + B.ncells - 1];
-    const int c_lo = cfirst.x0 + 3 - B.xa, c_hi = clast.x0 + clast.cw - 3 - B.xa;
+    const int c_lo = B.c_lo, c_hi = B.c_hi;
     const int t_lo = min(g.ini_th, g.min_th);
-    (void)FC_SURV;                                           // (rounds 1-2: rows per block of the pooled survivor list)
     // dwords that hold at least one detection column and have both neighbours inside the row
-    const int dw_lo = max(1, c_lo >> 2);
-    const int dw_hi = min(PW - 2, (c_hi - 1) >> 2);
+    const int dw_lo = B.dw_lo, dw_hi = B.dw_hi;
     if (tid < PW) {
         unsigned mk[4];
         for (int i = 0; i < 4; i++) mk[i] = (4 * tid + i >= c_lo && 4 * tid + i < c_hi) ? 0xFFFFu : 0u;
         colmask[tid] = make_uint2(mk[0] | (mk[2] << 16), mk[1] | (mk[3] << 16));
     }
-    FC_STAMP(5);                                             // (diagnostic: wave 0's own staging is issued; the barrier below waits for its data and the other waves)
     __syncthreads();
     FC_STAMP(1);
     if (abl == 1) return;                                    // staging only
     if (tid < P) {                                           // (read after the next barrier)
         int ci = 255;
-        for (int i = 0; i < B.ncells && i < FC_CELLS; i++) if (tid >= clo[i] && tid < clo[i] + cwd[i]) ci = i;
+#pragma unroll
+        for (int i = 0; i < ORB_BAND_CELLS; i++) if (i < bncells && tid >= bclo[i] && tid < bclo[i] + bcwd[i]) ci = i;
         colcell[tid] = (uint8_t)ci;
     }
     unsigned short* wsurv = surv + wv * WCAP;
@@ -693,18 +701,18 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     if (abl == 3) return;                                    // no NMS
     const int nnz = nsurv[1];
     const int rh = bh - 6;
-    bool listed = g.min_th <= g.ini_th && nnz <= FC_NZ && B.ncells <= FC_CELLS;
+    bool listed = g.min_th <= g.ini_th && nnz <= FC_NZ && bncells <= ORB_BAND_CELLS;
     if (listed) {
         // the local maxima go to one bucket of `kept` per cell, so that the row-major rank of a keypoint inside its
         // cell only scans the maxima of that cell (a fifth of the band's on the EuRoC-shaped frames)
-        const int cap_c = ((FC_KEPT / max(B.ncells, 1)) - 1) | 1;      // odd: the buckets start in different LDS banks
+        const int cap_c = ((FC_KEPT / max(bncells, 1)) - 1) | 1;      // odd: the buckets start in different LDS banks
         const unsigned p_inv = 0xFFFFFFFFu / (unsigned)P + 1u;           // pos / P == mulhi(pos, p_inv) for pos < 2^16 and every pitch 16..256 (checked exhaustively)
         for (int e = tid; e < nnz; e += FC_TPB) {
             const int pos = nz[e];
             const int row = (int)__umulhi((unsigned)pos, p_inv), col = pos - row * P;
             const int ci = colcell[col];
             if (ci == 255) continue;
-            const int xx = col - clo[ci], yy = row - 3, rw = cwd[ci];
+            const int xx = col - l_clo[ci], yy = row - 3, rw = l_cwd[ci];
             const uint8_t* p = S + pos;
             const int sc = p[0];
             const bool l = xx > 0, r = xx + 1 < rw, u = yy > 0, d = yy + 1 < rh;
@@ -721,18 +729,16 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         __syncthreads();
         FC_STAMP(3);
-        int nk = 0;
-        for (int i = 0; i < B.ncells; i++) {
-            const int k = cell_k[i];
-            listed = listed && k <= cap_c;
-            nk += k;
-        }
+        // (cell_k of the cells the band does not have is 0)
+        const int4 ck = *reinterpret_cast<const int4*>(cell_k);
+        const int e1 = ck.x, e2 = e1 + ck.y, e3 = e2 + ck.z, nk = e3 + ck.w;
+        listed = max(max(ck.x, ck.y), max(ck.z, ck.w)) <= cap_c;
         if (listed) {
             for (int e = tid; e < nk; e += FC_TPB) {
-                int ci = 0, k0 = e;
-                for (; k0 >= cell_k[ci]; ci++) k0 -= cell_k[ci];
+                const int ci = (e >= e1 ? 1 : 0) + (e >= e2 ? 1 : 0) + (e >= e3 ? 1 : 0);
+                const int k0 = e - (ci == 0 ? 0 : ci == 1 ? e1 : ci == 2 ? e2 : e3);
                 const unsigned* bucket = kept + ci * cap_c;
-                const int nb = cell_k[ci];
+                const int nb = ci == 0 ? ck.x : ci == 1 ? ck.y : ci == 2 ? ck.z : ck.w;
                 const unsigned me = bucket[k0];
                 const unsigned th = (unsigned)(cell_hi[ci] > 0 ? g.ini_th : g.min_th);      // :978-984: ini first, else min
                 if ((me & 255u) < th) continue;
@@ -741,19 +747,20 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                     const unsigned o = bucket[k];
                     rank += ((o & 255u) >= th && (o >> 8) < (me >> 8)) ? 1 : 0;
                 }
-                if (rank < ccap[ci])
-                    slots[(long long)f * g.slots_per_frame + cslot[ci] + rank] =
-                        ((me & 255u) << 24) | ((unsigned)(coy[ci] + (int)((me >> 14) & 63u)) << 12) | (unsigned)(cox[ci] + (int)((me >> 8) & 63u));
+                if (rank < l_scap[ci])
+                    slots[(long long)f * g.slots_per_frame + l_sfirst[ci] + rank] =
+                        ((me & 255u) << 24) | ((unsigned)(by0 + 3 - ORB_BORDER + (int)((me >> 14) & 63u)) << 12) |
+                        (unsigned)(bxa + l_clo[ci] - ORB_BORDER + (int)((me >> 8) & 63u));
             }
             // a cell's count = its local maxima at the chosen threshold: one thread per cell counts its bucket (an atomic per keypoint
             // and a barrier before the store, until round 3)
-            if (tid >= FC_TPB - FC_CELLS && FC_TPB - 1 - tid < B.ncells) {
+            if (tid >= FC_TPB - FC_CELLS && FC_TPB - 1 - tid < bncells) {
                 const int ci = FC_TPB - 1 - tid;
                 const unsigned th = (unsigned)(cell_hi[ci] > 0 ? g.ini_th : g.min_th);
                 const unsigned* bucket = kept + ci * cap_c;
                 int cnt = 0;
                 for (int k = 0; k < cell_k[ci]; k++) cnt += (bucket[k] & 255u) >= th ? 1 : 0;
-                cell_count[(long long)f * g.ncells + B.cell_first + ci] = cnt;
+                cell_count[(long long)f * g.ncells + bcfirst + ci] = cnt;
             }
             FC_STAMP(4);
             return;
@@ -1485,8 +1492,9 @@ void orb_launch_fast_cells(hipStream_t s, const OrbGeom& g_dev, const OrbCell* c
     // occupancy experiment (tools/r03_occupancy_sweep.sh): a larger LDS request leaves fewer workgroups per CU; results are unchanged
     static const size_t lds_min = getenv("CCM_FC_LDS_MIN") ? (size_t)atol(getenv("CCM_FC_LDS_MIN")) : 0;
     if (lds_bytes < lds_min) lds_bytes = lds_min;
-    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
-    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, surv_cap, abl, xcd_on);
+    (void)surv_cap;                                          // (rounds 1-2: size of the pooled survivor list)
+    if (packed) hipLaunchKernelGGL(k_fast_cells<true>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, 0, abl, xcd_on);
+    else hipLaunchKernelGGL(k_fast_cells<false>, dim3(nbands, nframes), dim3(FC_TPB), lds_bytes, s, g_dev, cells, bands, slots, cell_count, 0, abl, xcd_on);
 }
 size_t orb_fast_cells_lds(int pitch, int bh, int surv_cap) { return fc_lds_bytes(pitch, bh, surv_cap); }
 void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells, int nlevels, int nframes, int list_cap,

@@ -38,11 +38,26 @@ struct OrbCell {
     int slot_first, slot_cap;           // per-frame candidate slots of this cell
 };
 
-// One workgroup of the fused FAST kernel: a run of cells of one cell row (k_fast_cells)
+// A band of k_fast_cells: consecutive cells of one cell row of one level, with everything the kernel needs before it can request the
+// band's pixels -- one 64-byte scalar load.  (Until round 3 the kernel loaded a 16-byte band record, THEN the level record it
+// pointed to, THEN the first and last cell records, and computed two integer reciprocals: 3,700 cycles of dependent scalar work in
+// front of the pixel loads of a workgroup that lives 26,000.)
 struct OrbBand {
+    const uint8_t* img;                // level image base; nullptr for level 0, whose pointer, pitch and plane change per call (OrbGeom::lv[0])
+    long long plane;                   // bytes per frame of the level image
+    int lpitch, w, h;                  // level pitch and size
+    int level;
     int cell_first, ncells;            // consecutive cells of one row of one level
-    short level, xa, y0, pitch, bh, pad; // tile origin (xa multiple of 4, one spare dword left of the first cell), LDS pitch, rows
+    short xa, y0, pitch, bh;           // tile origin (xa multiple of 4, one spare dword left of the first cell), LDS pitch, rows
+    short c_lo, c_hi, dw_lo, dw_hi;    // detection columns of the tile [c_lo, c_hi); dwords with a detection column and both neighbours
+    unsigned pw_inv, pq_inv;           // floor(2^20 / (pitch / 4)) + 1, floor(2^20 / (pitch / 16)) + 1: i / PW and i / PQ by multiply-shift
+    // its (at most ORB_BAND_CELLS) cells: first detection column of the tile and number of detection columns, candidate slots of the cell
+    short clo[4], cwd[4];
+    int slot_first[4], slot_cap[4];
+    int pad_[4];
 };
+#define ORB_BAND_CELLS 4
+static_assert(sizeof(OrbBand) == 128, "two s_load_dwordx16");
 
 struct OrbGeom {
     int nlevels, ncells, ntiles;

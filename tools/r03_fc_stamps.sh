@@ -25,8 +25,8 @@ print("workgroups with stamps:", int(ok.sum()))
 names = ["start -> staged (barrier 1)", "staged -> every pixel scored (wave-local rejection + scoring, barrier 2)",
          "scored -> local maxima listed", "local maxima -> written (end)"]
 seq = [(0, 1), (1, 2), (2, 3), (3, 4)]
-print("  start -> band descriptor arrived: median %.0f; -> this wave's pixels arrived and stored: median %.0f; -> rest of the set-up (cell records, masks): median %.0f" % (np.median(b[:, 6] - b[:, 0]), np.median(b[:, 7] - b[:, 6]), np.median(b[:, 5] - b[:, 7])))
-d5 = b[:, 5] - b[:, 0]; print("  of the first phase: start -> wave 0 has issued its staging (loads requested, LDS stores issued): median %.0f mean %.0f; then the barrier: median %.0f" % (np.median(d5), d5.mean(), np.median(b[:, 1] - b[:, 5])))
+print("  start -> band descriptor arrived: median %.0f; -> level record etc. arrived, pixel loads can be issued: median %.0f; -> this wave's pixels arrived and stored: median %.0f; -> rest of the set-up + barrier: median %.0f" % (
+      np.median(b[:, 6] - b[:, 0]), np.median(b[:, 5] - b[:, 6]), np.median(b[:, 7] - b[:, 5]), np.median(b[:, 1] - b[:, 7])))
 tot = (b[:, 4] - b[:, 0])
 print("s_memtime ticks (100 MHz constant clock? or shader clock): total median %.0f  mean %.0f" % (np.median(tot), tot.mean()))
 for nm, (a, c) in zip(names, seq):

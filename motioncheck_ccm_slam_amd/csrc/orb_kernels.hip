@@ -1294,17 +1294,57 @@ __device__ __forceinline__ unsigned od_dot2(unsigned a, unsigned w, unsigned acc
 }
 
 #ifndef OD_WAVES
-#define OD_WAVES 4               // keypoints (waves) per workgroup
+#define OD_WAVES 4               // waves per workgroup
 #endif
+#ifndef OD_ITEMS
+#define OD_ITEMS 8               // keypoint slots per wave (2 / 4 / 8 measured: step 1.070 / 1.061 / 1.049 ms, from 1.125 with one)
+#endif
+// A wave works through OD_ITEMS slots.  Until round 3 it took one and ended: every keypoint then paid the workgroup launch, the
+// weight tables, and the chain slot -> key -> level record -> 11 row loads before its first useful instruction, ~3,500 cycles of a
+// lifetime of 23,000 in which the wave held one of the CU's 32 wave slots (profiles/r03_occupancy_sweep.txt: the kernel issues for
+// 0.56 of its time at full occupancy).  Now the slots of a wave are decoded together (one lane per slot), and the patch rows of the
+// NEXT keypoint are requested as soon as the horizontal blur has consumed the current ones -- into the same registers -- so they
+// arrive under the vertical blur and the descriptor.
+struct OdItem { const uint8_t* img; int pitch, w, h, cx, cy; };
+__device__ __forceinline__ void od_load_patch(const OdItem& it, int lane, unsigned (&prow)[11])
+{
+    const int gy = reflect101(it.cy + min(lane, ORB_PATCH_D - 1) - ORB_PATCH_R, it.h);
+    const uint8_t* rp = it.img + (long long)gy * it.pitch;
+    if (it.cx - ORB_PATCH_R >= 0 && it.cx + ORB_PATCH_R + 1 < it.w) {     // wave-uniform: patch inside the row
+        const uint8_t* p0 = rp + it.cx - ORB_PATCH_R;
+#pragma unroll
+        for (int i = 0; i < 11; i++) __builtin_memcpy(&prow[i], p0 + 4 * i, 4);   // unaligned dword loads
+    } else {                                                               // BORDER_REFLECT_101 columns
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            unsigned v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (unsigned)rp[reflect101(it.cx + 4 * i + j - ORB_PATCH_R, it.w)] << (8 * j);
+            prow[i] = v;
+        }
+    }
+}
 __global__ __launch_bounds__(64 * OD_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
                                                      const int* __restrict__ sel_count,
                                                      ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                      int* __restrict__ counts, int max_per_image, int* __restrict__ status, int xcd_on)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t od_pad[];      // (occupancy experiment only: CCM_OD_LDS_PAD)
     __shared__ __attribute__((aligned(16))) uint8_t lds[OD_WAVES][OD_WAVE_LDS_PAD];
     // IC_Angle weights per |v| and patch dword k (columns 4k..4k+3, u = column - 21):
     //   wone = 1 inside the disc row, wu = u + 16 inside (so that sum u*I = dot(wu) - 16*dot(wone) stays unsigned)
-    __shared__ unsigned wone[16][11], wu[16][11];
+    __shared__ unsigned wone[16][11], wu[16][11], pat[256];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    int wx, wy;
+    xcd_work_item(xcd_on, wx, wy);
+    const int f = wy + g.frame0;
+    // ---- this wave's slots, one per lane: slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
+    const int* sc = sel_count + (long long)f * g.nlevels;
+    const int slot = (wx * OD_ITEMS + min(lane, OD_ITEMS - 1)) * OD_WAVES + wv;
+    const unsigned key_l = slot < g.out_per_frame ? sel[(long long)f * g.out_per_frame + slot] : 0u;     // (requested before the tables are built)
+    // the 256 test pairs (x0, y0, x1, y1 as signed bytes): read from LDS per keypoint (as global loads they put a wait for ALL of the
+    // wave's outstanding memory operations, the previous descriptor stores included, in front of each of the four rounds)
+    for (int i = threadIdx.x; i < 256; i += 64 * OD_WAVES) pat[i] = *reinterpret_cast<const unsigned*>(c_pattern + 4 * i);
     for (int i = threadIdx.x; i < 16 * 11; i += 64 * OD_WAVES) {
         const int av = i / 11, k = i - av * 11;
         const int lim = g.umax[av];
@@ -1315,145 +1355,145 @@ __global__ __launch_bounds__(64 * OD_WAVES) __attribute__((amdgpu_waves_per_eu(8
         }
         wone[av][k] = a; wu[av][k] = b;
     }
-    __syncthreads();
-    const int wv = threadIdx.x >> 6, lane = lane_id();
-    int wx, wy;
-    xcd_work_item(xcd_on, wx, wy);
-    const int slot = wx * OD_WAVES + wv, f = wy + g.frame0;
-    if (slot >= g.out_per_frame) return;
-    // slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
-    int level = 0;
-    for (int l = 1; l < g.nlevels; l++) if (slot >= g.lv[l].out_first) level = l;
-    const OrbLevel& L = g.lv[level];
-    const int k = slot - L.out_first;
-    const int* sc = sel_count + (long long)f * g.nlevels;
-    int row = k, tot = 0;
-    for (int l = 0; l < g.nlevels; l++) { const int c = sc[l]; if (l < level) row += c; tot += c; }
-    if (slot == 0 && lane == 0) {
+    int level_l = 0, first_l = 0;
+    for (int l = 1; l < g.nlevels; l++) if (slot >= g.lv[l].out_first) { level_l = l; first_l = g.lv[l].out_first; }
+    int row_l = slot - first_l, tot = 0, cnt_l = 0;
+    for (int l = 0; l < g.nlevels; l++) { const int c = sc[l]; if (l < level_l) row_l += c; if (l == level_l) cnt_l = c; tot += c; }
+    if (wx == 0 && wv == 0 && lane == 0) {
         counts[f] = min(tot, max_per_image);
         if (tot > max_per_image) atomicOr(status, 8);
     }
-    const unsigned key = sel[(long long)f * g.out_per_frame + slot];      // issued before the count-dependent exit
-    if (k >= sc[level] || row >= max_per_image) return;
-
-    const int cx = (int)(key & 0xFFFu) + ORB_BORDER, cy = (int)((key >> 12) & 0xFFFu) + ORB_BORDER;   // :1012-1013
-    const int score = (int)(key >> 24);
-
-    // ---- lane r < 43 holds patch row r (43 pixels + 1 spare byte) in 11 registers
-    unsigned prow[11];
-    {
-        const uint8_t* img = L.img + (long long)f * L.plane;
-        const int gy = reflect101(cy + min(lane, ORB_PATCH_D - 1) - ORB_PATCH_R, L.h);
-        const uint8_t* rp = img + (long long)gy * L.pitch;
-        if (cx - ORB_PATCH_R >= 0 && cx + ORB_PATCH_R + 1 < L.w) {           // wave-uniform: patch inside the row
-            const uint8_t* p0 = rp + cx - ORB_PATCH_R;
-#pragma unroll
-            for (int i = 0; i < 11; i++) __builtin_memcpy(&prow[i], p0 + 4 * i, 4);   // unaligned dword loads
-        } else {                                                               // BORDER_REFLECT_101 columns
-#pragma unroll
-            for (int i = 0; i < 11; i++) {
-                unsigned v = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) v |= (unsigned)rp[reflect101(cx + 4 * i + j - ORB_PATCH_R, L.w)] << (8 * j);
-                prow[i] = v;
-            }
-        }
-    }
-
-    // ---- IC_Angle: integer moments over the radius-15 disc, one row per lane
-    int m10 = 0, m01 = 0;
-    {
-        const int v = lane - ORB_PATCH_R, av = v < 0 ? -v : v;
-        if (av <= ORB_HALF_PATCH) {
-            unsigned s1 = 0, su = 0;
-#pragma unroll
-            for (int i = 1; i < 10; i++) {          // columns 4..39 cover u = -15..15 (columns 6..36)
-                s1 = __builtin_amdgcn_udot4(prow[i], wone[av][i], s1, false);
-                su = __builtin_amdgcn_udot4(prow[i], wu[av][i], su, false);
-            }
-            m10 = (int)su - 16 * (int)s1;
-            m01 = v * (int)s1;
-        }
-    }
-    m10 = wave_sum(m10); m01 = wave_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    const bool valid_l = lane < OD_ITEMS && slot < g.out_per_frame && slot - first_l < cnt_l && row_l < max_per_image;
+    unsigned long long todo = __ballot(valid_l);
+    __syncthreads();                                                       // (the weight tables)
+    if (todo == 0) return;
 
     uint8_t* wl = lds[wv];
     uint8_t* bl = wl;                                  // overlays hT, see OD_WAVE_LDS
-    // ---- horizontal 7 taps {18,34,49,55,49,34,18}: two v_dot4_u32_u8 per output, written transposed
-    if (lane < ORB_PATCH_D) {
-        const unsigned Q0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), Q1 = 49u | (34u << 8) | (18u << 16);
-#pragma unroll
-        for (int x = 0; x < ORB_BLUR_D; x++) {
-            const int kk = x >> 2, sh = x & 3;
-            const unsigned w0 = sh ? __builtin_amdgcn_alignbyte(prow[kk + 1], prow[kk], sh) : prow[kk];
-            const unsigned w1 = sh ? __builtin_amdgcn_alignbyte(prow[kk + 2 > 10 ? 10 : kk + 2], prow[kk + 1], sh) : prow[kk + 1];
-            const unsigned h = __builtin_amdgcn_udot4(w1, Q1, __builtin_amdgcn_udot4(w0, Q0, 0u, false), false);   // <= 65535
-            *reinterpret_cast<unsigned short*>(wl + x * OD_HT_PITCH + 2 * lane) = (unsigned short)h;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    // ---- vertical 7 taps + the single rounding.  An item is a third of a blurred column (rows 12t .. 12t+12; the
-    //      13th row of the first two thirds is also the first of the next: same value, written twice): 111 items in
-    //      two rounds of 64 lanes = 26 outputs per lane instead of 37.  Rows are packed two per dword, so four
-    //      v_dot2_u32_u16 make one output; a third starts on an even row, so the tap layout is the same for all.
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    auto item_of = [&](int j, OdItem& it, int& level, int& score, int& row) {
+        const unsigned key = (unsigned)__builtin_amdgcn_readlane((int)key_l, j);
+        level = __builtin_amdgcn_readlane(level_l, j); row = __builtin_amdgcn_readlane(row_l, j);
+        const OrbLevel& L = g.lv[level];
+        it.img = L.img + (long long)f * L.plane; it.pitch = L.pitch; it.w = L.w; it.h = L.h;
+        it.cx = (int)(key & 0xFFFu) + ORB_BORDER; it.cy = (int)((key >> 12) & 0xFFFu) + ORB_BORDER;   // :1012-1013
+        score = (int)(key >> 24);
+    };
+    // ---- lane r < 43 holds patch row r (43 pixels + 1 spare byte) in 11 registers
+    unsigned prow[11];
+    OdItem it; int level, score, row;
     {
-        unsigned d[2][10];
-        int wofs[2];
+        const int j = __builtin_ctzll(todo); todo &= todo - 1;
+        item_of(j, it, level, score, row);
+        od_load_patch(it, lane, prow);
+    }
+    for (;;) {
+        // ---- IC_Angle: integer moments over the radius-15 disc, one row per lane
+        int m10 = 0, m01 = 0;
+        {
+            const int v = lane - ORB_PATCH_R, av = v < 0 ? -v : v;
+            if (av <= ORB_HALF_PATCH) {
+                unsigned s1 = 0, su = 0;
 #pragma unroll
-        for (int rd = 0; rd < 2; rd++) {
-            const int item = min(rd * 64 + lane, 3 * ORB_BLUR_D - 1);
-            const int c = (item * 171) >> 9, t = item - 3 * c;                 // item / 3 for item < 128
-            const unsigned* col = reinterpret_cast<const unsigned*>(wl + c * OD_HT_PITCH) + 6 * t;
-#pragma unroll
-            for (int i = 0; i < 10; i++) d[rd][i] = col[i];
-            wofs[rd] = 12 * t * OD_B_PITCH + c;
+                for (int i = 1; i < 10; i++) {          // columns 4..39 cover u = -15..15 (columns 6..36)
+                    s1 = __builtin_amdgcn_udot4(prow[i], wone[av][i], s1, false);
+                    su = __builtin_amdgcn_udot4(prow[i], wu[av][i], su, false);
+                }
+                m10 = (int)su - 16 * (int)s1;
+                m01 = v * (int)s1;
+            }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // every column is in registers before bl overwrites hT
+        m10 = wave_sum(m10); m01 = wave_sum(m01);
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+        // ---- horizontal 7 taps {18,34,49,55,49,34,18}: two v_dot4_u32_u8 per output, written transposed
+        if (lane < ORB_PATCH_D) {
+            const unsigned Q0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), Q1 = 49u | (34u << 8) | (18u << 16);
+#pragma unroll
+            for (int x = 0; x < ORB_BLUR_D; x++) {
+                const int kk = x >> 2, sh = x & 3;
+                const unsigned w0 = sh ? __builtin_amdgcn_alignbyte(prow[kk + 1], prow[kk], sh) : prow[kk];
+                const unsigned w1 = sh ? __builtin_amdgcn_alignbyte(prow[kk + 2 > 10 ? 10 : kk + 2], prow[kk + 1], sh) : prow[kk + 1];
+                const unsigned h = __builtin_amdgcn_udot4(w1, Q1, __builtin_amdgcn_udot4(w0, Q0, 0u, false), false);   // <= 65535
+                *reinterpret_cast<unsigned short*>(wl + x * OD_HT_PITCH + 2 * lane) = (unsigned short)h;
+            }
+        }
+        // ---- the next keypoint's rows, into the registers the horizontal pass has just finished with
+        const bool more = todo != 0;
+        const int cx = it.cx, cy = it.cy, level_c = level, score_c = score, row_c = row;
+        if (more) {
+            const int j = __builtin_ctzll(todo); todo &= todo - 1;
+            item_of(j, it, level, score, row);
+            od_load_patch(it, lane, prow);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
+        // ---- vertical 7 taps + the single rounding.  An item is a third of a blurred column (rows 12t .. 12t+12; the
+        //      13th row of the first two thirds is also the first of the next: same value, written twice): 111 items in
+        //      two rounds of 64 lanes = 26 outputs per lane instead of 37.  Rows are packed two per dword, so four
+        //      v_dot2_u32_u16 make one output; a third starts on an even row, so the tap layout is the same for all.
+        {
+            unsigned d[2][10];
+            int wofs[2];
 #pragma unroll
-        for (int rd = 0; rd < 2; rd++) {
-            if (rd * 64 + lane < 3 * ORB_BLUR_D) {
+            for (int rd = 0; rd < 2; rd++) {
+                const int item = min(rd * 64 + lane, 3 * ORB_BLUR_D - 1);
+                const int c = (item * 171) >> 9, t = item - 3 * c;                 // item / 3 for item < 128
+                const unsigned* col = reinterpret_cast<const unsigned*>(wl + c * OD_HT_PITCH) + 6 * t;
 #pragma unroll
-                for (int y = 0; y < 13; y++) {
-                    const int kk = y >> 1;
-                    unsigned v;
-                    if ((y & 1) == 0)
-                        v = od_dot2(d[rd][kk + 3], 18u, od_dot2(d[rd][kk + 2], 49u | (34u << 16), od_dot2(d[rd][kk + 1], 49u | (55u << 16), od_dot2(d[rd][kk], 18u | (34u << 16), 32768u))));
-                    else
-                        v = od_dot2(d[rd][kk + 3], 34u | (18u << 16), od_dot2(d[rd][kk + 2], 55u | (49u << 16), od_dot2(d[rd][kk + 1], 34u | (49u << 16), od_dot2(d[rd][kk], 18u << 16, 32768u))));
-                    bl[wofs[rd] + y * OD_B_PITCH] = (uint8_t)min(v >> 16, 255u);     // the rounding constant 32768 is the accumulator's start value
+                for (int i = 0; i < 10; i++) d[rd][i] = col[i];
+                wofs[rd] = 12 * t * OD_B_PITCH + c;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                // every column is in registers before bl overwrites hT
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int rd = 0; rd < 2; rd++) {
+                if (rd * 64 + lane < 3 * ORB_BLUR_D) {
+#pragma unroll
+                    for (int y = 0; y < 13; y++) {
+                        const int kk = y >> 1;
+                        unsigned v;
+                        if ((y & 1) == 0)
+                            v = od_dot2(d[rd][kk + 3], 18u, od_dot2(d[rd][kk + 2], 49u | (34u << 16), od_dot2(d[rd][kk + 1], 49u | (55u << 16), od_dot2(d[rd][kk], 18u | (34u << 16), 32768u))));
+                        else
+                            v = od_dot2(d[rd][kk + 3], 34u | (18u << 16), od_dot2(d[rd][kk + 2], 55u | (49u << 16), od_dot2(d[rd][kk + 1], 34u | (49u << 16), od_dot2(d[rd][kk], 18u << 16, 32768u))));
+                        bl[wofs[rd] + y * OD_B_PITCH] = (uint8_t)min(v >> 16, 255u);     // the rounding constant 32768 is the accumulator's start value
+                    }
                 }
             }
         }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
 
-    // ---- steered BRIEF: lane L evaluates pairs L, 64+L, 128+L, 192+L; a ballot is 8 descriptor bytes
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    ccm_sincosf(angle * factorPI, &b, &a);
-    uint8_t* drow = desc + ((long long)f * max_per_image + row) * 32;
-    const uint8_t* ctr = bl + 18 * OD_B_PITCH + 18;
+        // ---- steered BRIEF: lane L evaluates pairs L, 64+L, 128+L, 192+L; a ballot is 8 descriptor bytes
+        float a, b;
+        ccm_sincosf(angle * factorPI, &b, &a);
+        uint8_t* drow = desc + ((long long)f * max_per_image + row_c) * 32;
+        const uint8_t* ctr = bl + 18 * OD_B_PITCH + 18;
+        unsigned long long mybits = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const signed char* pp = c_pattern + 4 * (r * 64 + lane);
-        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-        const int t0 = ctr[__float2int_rn(x0 * b + y0 * a) * OD_B_PITCH + __float2int_rn(x0 * a - y0 * b)];
-        const int t1 = ctr[__float2int_rn(x1 * b + y1 * a) * OD_B_PITCH + __float2int_rn(x1 * a - y1 * b)];
-        const unsigned long long bits = __ballot(t0 < t1);
-        if (lane == 0) *reinterpret_cast<unsigned long long*>(drow + 8 * r) = bits;
-    }
-    if (lane == 0) {
-        ccm_keypoint kp;
-        kp.x = (float)cx; kp.y = (float)cy;
-        if (level != 0) { kp.x *= L.scale; kp.y *= L.scale; }              // :1268-1274
-        kp.size = L.kp_size; kp.angle = angle; kp.response = (float)score;
-        kp.octave = level; kp.class_id = -1;
-        kps[(long long)f * max_per_image + row] = kp;
+        for (int r = 0; r < 4; r++) {
+            const unsigned pr = pat[r * 64 + lane];
+            const float x0 = (float)(signed char)(pr & 255u), y0 = (float)(signed char)((pr >> 8) & 255u);
+            const float x1 = (float)(signed char)((pr >> 16) & 255u), y1 = (float)(signed char)(pr >> 24);
+            const int t0 = ctr[__float2int_rn(x0 * b + y0 * a) * OD_B_PITCH + __float2int_rn(x0 * a - y0 * b)];
+            const int t1 = ctr[__float2int_rn(x1 * b + y1 * a) * OD_B_PITCH + __float2int_rn(x1 * a - y1 * b)];
+            const unsigned long long bits = __ballot(t0 < t1);
+            if (lane == r) mybits = bits;
+        }
+        if (lane < 4) *reinterpret_cast<unsigned long long*>(drow + 8 * lane) = mybits;      // one 32-byte store
+        if (lane == 0) {
+            const OrbLevel& L = g.lv[level_c];
+            ccm_keypoint kp;
+            kp.x = (float)cx; kp.y = (float)cy;
+            if (level_c != 0) { kp.x *= L.scale; kp.y *= L.scale; }              // :1268-1274
+            kp.size = L.kp_size; kp.angle = angle; kp.response = (float)score_c;
+            kp.octave = level_c; kp.class_id = -1;
+            kps[(long long)f * max_per_image + row_c] = kp;
+        }
+        if (!more) break;
+        // (the BRIEF reads of bl are in registers -- the ballots consumed them -- before the next horizontal pass overwrites it)
     }
 }
 
@@ -1510,6 +1550,6 @@ void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_fra
 {
     static const int xcd_on = getenv("CCM_ORB_XCD_OD") ? atoi(getenv("CCM_ORB_XCD_OD")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 1);
     static const size_t lds_pad = getenv("CCM_OD_LDS_PAD") ? (size_t)atol(getenv("CCM_OD_LDS_PAD")) : 0;     // occupancy experiment only
-    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + OD_WAVES - 1) / OD_WAVES, nframes), dim3(64 * OD_WAVES), lds_pad, s,
+    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + OD_WAVES * OD_ITEMS - 1) / (OD_WAVES * OD_ITEMS), nframes), dim3(64 * OD_WAVES), lds_pad, s,
                        g_dev, sel, sel_count, kps, desc, counts, max_per_image, status, xcd_on);
 }

@@ -432,6 +432,12 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 // are staged once in LDS, scored in LDS (rejection test -> survivor list -> dense scoring, in row blocks), and
 // each cell's threshold choice / 3x3 NMS / ordered compaction runs straight from the LDS score tile: the score
 // map never goes to HBM.  Bands of adjacent cell rows overlap by 6 rows, which are scored twice.
+// One band per workgroup.  Round 3 built the alternative -- a workgroup loops over 1..8 consecutive bands and requests the next
+// band's pixels (8 registers per thread, one branch-free 16-byte global load per chunk) as soon as the current band is scored, so
+// that they arrive under the NMS -- and measured it on one box against this kernel (tools/ab_orb.sh): 0.391 ms at 1 band per
+// workgroup, 0.410 / 0.421 / 0.424 / 0.436 / 0.448 at 2 / 3 / 4 / 6 / 8, against 0.368.  A round of the loop (the extra barrier, the
+// band record and the kernel arguments re-read through scalar loads, 64 registers instead of 54) costs more than a fresh workgroup,
+// whose start-up the dispatcher overlaps with the seven others on the CU.  Not kept.
 // the survivor list holds `surv_cap` pixels; the detection rows are processed in blocks of surv_cap / pitch rows
 // NMS works on the list of scored pixels (FC_NZ entries) and the list of local maxima (FC_KEPT); a band that overflows
 // either list takes the per-cell row scan instead.

@@ -162,8 +162,19 @@ template <int NWV>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sp_schur_blocks(BaDev D, const double* __restrict__ Y, const unsigned long long* __restrict__ pairs,
                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                                                          const int* __restrict__ blk_row, const int* __restrict__ blk_col, int nb,
-                                                         double* __restrict__ Hb)
+                                                         double* __restrict__ Hb, int per_xcd)
 {
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The blocks are sorted by (row, column): in dispatch order
+    // the ~57 blocks of a block row -- which all gather the row keyframe's Z blocks, and whose column keyframes are the next row's too --
+    // are spread over all eight L2s, and every one of them fetches the same operands from the fabric.  per_xcd < 0 (shipped: -64): chunks
+    // of -per_xcd consecutive block pairs go to one XCD, chunk c to XCD c % 8; per_xcd > 0: XCD x takes the contiguous range
+    // [x per_xcd, (x + 1) per_xcd) (twice as slow as dispatch order: sp_launch_schur_blocks has the measurements).
+    int wg = (int)blockIdx.x;
+    if (per_xcd > 0) wg = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    else if (per_xcd < 0) {                                  // chunk-cyclic: -per_xcd consecutive block pairs to one XCD
+        const int C = -per_xcd, xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        wg = ((j / C) * 8 + xcd) * C + j % C;
+    }
     // TWO reduced blocks per workgroup share the 16 x 16 tile of the MFMA: operand rows 0..5 belong to block 2 g, rows 8..13 to block
     // 2 g + 1 (each with its own pair list), and the tile's two diagonal 6 x 6 corners are the two sums (the off-diagonal corners mix the
     // blocks and are dropped).  The same number of gather loads now serves two blocks: 48 of 64 lanes load instead of 24.
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;              // operand row of the tile, k within an MFMA
     const int half = i16 >> 3, i = i16 & 7;                 // which of the two blocks, row inside it (< 6 used)
-    const int b = 2 * (int)blockIdx.x + half;
+    const int b = 2 * wg + half;
     const bool live = i < 6 && b < nb;
     const int p0 = live ? seg_start[b] : 0, p1 = live ? seg_end[b] : 0;
     // the longer of the workgroup's two lists sets the trip count (wave-uniform)
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     __syncthreads();
     if (threadIdx.x < 72) {
-        const int h2 = threadIdx.x / 36, e = threadIdx.x - 36 * h2, bb = 2 * (int)blockIdx.x + h2;
+        const int h2 = threadIdx.x / 36, e = threadIdx.x - 36 * h2, bb = 2 * wg + h2;
         if (bb < nb) {
             const int rb = blk_row[bb], cb = blk_col[bb];
             const double base = rb == cb ? D.Hpp[36 * (long long)rb + e] : 0.0;
@@ -1407,8 +1418,15 @@ void sp_launch_schur_blocks(hipStream_t s, const BaDev& D, const double* Y, cons
 {
     // few blocks with long pair lists (a local BA: 210 blocks of ~1000 pairs) get 16 waves per block, maps with many blocks 4
     if (nb <= 0) return;
-    if (nb < 2048) hipLaunchKernelGGL(k_sp_schur_blocks<16>, dim3((nb + 1) / 2), dim3(1024), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
-    else hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3((nb + 1) / 2), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb);
+    // measured (config 5, Schur phase of optimize(20), tools/bench_gba.py): dispatch order 4.67 ms, contiguous eighths 8.73 (each XCD then
+    // works on a handful of rows at a time and their operands sit in a few L2 channels), chunks of 4 / 16 / 64 / 512 block pairs
+    // 4.53 / 4.14 / 4.00 / 4.36
+    static const int xcd = getenv("CCM_SP_XCD") ? atoi(getenv("CCM_SP_XCD")) : 64;     // 0 dispatch order, 1 contiguous eighths, C > 1 chunks of C
+    const int nwg = (nb + 1) / 2, per = (nwg + 7) / 8;
+    if (nb < 2048) hipLaunchKernelGGL(k_sp_schur_blocks<16>, dim3(nwg), dim3(1024), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb, 0);
+    else if (xcd == 1) hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3(8 * per), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb, per);
+    else if (xcd > 1) hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3((nwg + 8 * xcd - 1) / (8 * xcd) * (8 * xcd)), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb, -xcd);
+    else hipLaunchKernelGGL(k_sp_schur_blocks<4>, dim3(nwg), dim3(256), 0, s, D, Y, pairs, st, en, br, bc, nb, Hb, 0);
 }
 void sp_launch_bschur(hipStream_t s, const BaDev& D, double* bs)
 {

@@ -1,7 +1,10 @@
-// Drop-in bodies of cslam::Optimizer's bundle-adjustment entry points (include/cslam/Optimizer.h:84-97).
+// Drop-in bodies of cslam::Optimizer (include/cslam/Optimizer.h:84-113): every static entry point.
 // Replaces in src/Optimizer.cpp: BundleAdjustmentClient (:32-164 + write-back :166-212), PoseOptimizationClient (:215-347),
-// LocalBundleAdjustmentClient (:349-644) and MapFusionGBA (:646-865): the map is flattened into the arrays ccm_ba_solve /
-// ccm_pose_optimize take, the result is written back where the reference writes it.  No g2o object is created.
+// LocalBundleAdjustmentClient (:349-644), MapFusionGBA (:646-865), OptimizeSim3 (:867-1062), OptimizeEssentialGraphLoopClosure
+// (:1064-1331) and OptimizeEssentialGraphMapFusion (:1333-1574): the map is flattened into the arrays ccm_ba_solve / ccm_pose_optimize /
+// ccm_optimize_sim3 / ccm_optimize_essential_graph take, the result is written back where the reference writes it.  No g2o optimizer,
+// vertex or edge is created; g2o::Sim3 (a header-only value type, and part of two of the signatures) is used for the measurements'
+// inverse and product so that they are the reference's own arithmetic.
 #include <cslam/Optimizer.h>
 #include <cslam/Converter.h>
 #include <cslam/Frame.h>
@@ -9,7 +12,12 @@
 #include <cslam/Map.h>
 #include <cslam/MapPoint.h>
 #include <unistd.h>
+#include <set>
+#include <utility>
+#include <vector>
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <list>
 #include <map>
 #include "ccm_shim.h"
@@ -215,6 +223,207 @@ int Optimizer::PoseOptimizationClient(Frame& F)
     for (int e = 0; e < n; e++) F.mvbOutlier[feat[e]] = outlier[e] != 0;      // :318-333
     F.SetPose(pose_mat(pose7));                                               // :341-344
     return nInliers;                                                          // nInitialCorrespondences - nBad
+}
+
+
+// ---- Sim3 problems of loop closing and map fusion
+namespace {
+void sim3_to8(const g2o::Sim3& S, double* o)
+{
+    const Eigen::Quaterniond& q = S.rotation();
+    o[0] = q.x(); o[1] = q.y(); o[2] = q.z(); o[3] = q.w();
+    o[4] = S.translation()[0]; o[5] = S.translation()[1]; o[6] = S.translation()[2]; o[7] = S.scale();
+}
+g2o::Sim3 sim3_from8(const double* o)
+{
+    return g2o::Sim3(Eigen::Quaterniond(o[3], o[0], o[1], o[2]), Eigen::Vector3d(o[4], o[5], o[6]), o[7]);
+}
+}  // namespace
+
+int Optimizer::OptimizeSim3(kfptr pKF1, kfptr pKF2, std::vector<mpptr>& vpMatches1, g2o::Sim3& g2oS12, const float th2, bool bFixScale)
+{
+    const cv::Mat& K1 = pKF1->mK;
+    const cv::Mat& K2 = pKF2->mK;
+    const cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    const int N = (int)vpMatches1.size();
+    const std::vector<mpptr> vpMapPoints1 = pKF1->GetMapPointMatches();
+    std::vector<double> P1, P2, obs1, obs2, info1, info2;
+    std::vector<size_t> vnIndexEdge;
+    for (int i = 0; i < N; i++) {                                             // :918-990
+        if (!vpMatches1[i]) continue;
+        const mpptr pMP1 = vpMapPoints1[i], pMP2 = vpMatches1[i];
+        const int i2 = pMP2->GetIndexInKeyFrame(pKF2);
+        if (!pMP1 || !pMP2 || pMP1->isBad() || pMP2->isBad() || i2 < 0) continue;
+        const cv::Mat P3D1c = R1w * pMP1->GetWorldPos() + t1w, P3D2c = R2w * pMP2->GetWorldPos() + t2w;
+        for (int k = 0; k < 3; k++) { P1.push_back(P3D1c.at<float>(k)); P2.push_back(P3D2c.at<float>(k)); }
+        const cv::KeyPoint& kpUn1 = pKF1->mvKeysUn[i];
+        const cv::KeyPoint& kpUn2 = pKF2->mvKeysUn[i2];
+        obs1.push_back(kpUn1.pt.x); obs1.push_back(kpUn1.pt.y); info1.push_back(pKF1->mvInvLevelSigma2[kpUn1.octave]);
+        obs2.push_back(kpUn2.pt.x); obs2.push_back(kpUn2.pt.y); info2.push_back(pKF2->mvInvLevelSigma2[kpUn2.octave]);
+        vnIndexEdge.push_back(i);
+    }
+    const int nC = (int)vnIndexEdge.size();
+    double S[8], S0[8];
+    sim3_to8(g2oS12, S);
+    memcpy(S0, S, sizeof S);
+    const int32_t fix = bFixScale ? 1 : 0, first[2] = { 0, nC };
+    const double k1[4] = { K1.at<float>(0, 0), K1.at<float>(1, 1), K1.at<float>(0, 2), K1.at<float>(1, 2) };
+    const double k2[4] = { K2.at<float>(0, 0), K2.at<float>(1, 1), K2.at<float>(0, 2), K2.at<float>(1, 2) };
+    std::vector<uint8_t> inlier(std::max(nC, 1), 0);
+    int32_t nIn = 0;
+    ccm_sim3_problem pr{};
+    pr.n_problems = 1; pr.sim3 = S; pr.fix_scale = &fix; pr.K1 = k1; pr.K2 = k2; pr.first = first;
+    pr.P1 = P1.data(); pr.P2 = P2.data(); pr.obs1 = obs1.data(); pr.obs2 = obs2.data(); pr.info1 = info1.data(); pr.info2 = info2.data();
+    pr.th2 = &th2; pr.inlier = inlier.data(); pr.n_inliers = &nIn;
+    if (ccm_optimize_sim3(ccm_shim::ctx(), &pr)) throw estd::infrastructure_ex();
+    // :1015-1058: an outlier of either round loses its match; with fewer than 10 survivors of the first round the reference returns 0
+    // before the second (the first round's outliers are already nulled, g2oS12 untouched): inlier[] and sim3 come back that way
+    for (int e = 0; e < nC; e++) if (!inlier[e]) vpMatches1[vnIndexEdge[e]] = static_cast<mpptr>(NULL);
+    if (memcmp(S, S0, sizeof S) != 0) g2oS12 = sim3_from8(S);              // (left alone on the early return)
+    return nIn;
+}
+
+namespace {
+// both essential-graph entry points: the map-fusion one is the loop-closure one without Sim3 maps and with the _MM correction marks
+void essential_graph(Optimizer::mapptr pMap, Optimizer::kfptr pLoopKF, Optimizer::kfptr pCurKF, const Optimizer::KeyFrameAndPose* NonCorrectedSim3,
+                     const Optimizer::KeyFrameAndPose* CorrectedSim3, const std::map<Optimizer::kfptr, std::set<Optimizer::kfptr> >& LoopConnections,
+                     bool bFixScale, bool map_fusion)
+{
+    typedef Optimizer::kfptr kfptr;
+    typedef Optimizer::mpptr mpptr;
+    typedef Optimizer::KeyFrameAndPose KeyFrameAndPose;
+    const std::vector<kfptr> vpKFs = pMap->GetAllKeyFrames();
+    const std::vector<mpptr> vpMPs = pMap->GetAllMapPoints();
+    const unsigned int nMaxKFid = pMap->GetMaxKFidUnique();
+    std::vector<g2o::Sim3, Eigen::aligned_allocator<g2o::Sim3> > vScw(nMaxKFid + 1);
+    std::vector<int32_t> vertex_of(nMaxKFid + 1, -1);                           // mUniqueId -> vertex of the flat problem
+    const int minFeat = params::opt::miEssGraphMinFeats;
+    std::vector<double> sim3;                                                   // [n_vertices][8]
+    std::vector<uint8_t> fixed;
+    // ---- keyframe vertices (:1086-1121)
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        const kfptr pKF = vpKFs[i];
+        if (pKF->isBad()) continue;
+        const size_t nIDi = pKF->mUniqueId;
+        KeyFrameAndPose::const_iterator it;
+        if (CorrectedSim3 && (it = CorrectedSim3->find(pKF)) != CorrectedSim3->end()) vScw[nIDi] = it->second;
+        else vScw[nIDi] = g2o::Sim3(Converter::toMatrix3d(pKF->GetRotation()), Converter::toVector3d(pKF->GetTranslation()), 1.0);
+        vertex_of[nIDi] = (int32_t)fixed.size();
+        sim3.resize(sim3.size() + 8);
+        sim3_to8(vScw[nIDi], &sim3[sim3.size() - 8]);
+        fixed.push_back(pKF == pLoopKF ? 1 : 0);
+    }
+    const std::vector<double> sim3_before = sim3;
+    std::vector<int32_t> ei, ej;
+    std::vector<double> meas;
+    // an edge whose end has no vertex (a bad keyframe) is not added: g2o refuses an edge with a null vertex
+    auto add_edge = [&](size_t nIDi, size_t nIDj, const g2o::Sim3& Sji) {
+        if (vertex_of[nIDi] < 0 || vertex_of[nIDj] < 0) return;
+        ei.push_back(vertex_of[nIDi]); ej.push_back(vertex_of[nIDj]);
+        meas.resize(meas.size() + 8);
+        sim3_to8(Sji, &meas[meas.size() - 8]);
+    };
+    auto non_corrected = [&](const kfptr& k) -> const g2o::Sim3* {
+        if (!NonCorrectedSim3) return nullptr;
+        KeyFrameAndPose::const_iterator it = NonCorrectedSim3->find(k);
+        return it != NonCorrectedSim3->end() ? &it->second : nullptr;
+    };
+    std::set<std::pair<long unsigned int, long unsigned int> > sInsertedEdges;
+    // ---- loop edges (:1127-1157)
+    for (std::map<kfptr, std::set<kfptr> >::const_iterator mit = LoopConnections.begin(); mit != LoopConnections.end(); ++mit) {
+        const kfptr pKF = mit->first;
+        if (pKF->isBad()) continue;
+        const size_t nIDi = pKF->mUniqueId;
+        const g2o::Sim3 Swi = vScw[nIDi].inverse();
+        for (std::set<kfptr>::const_iterator sit = mit->second.begin(); sit != mit->second.end(); ++sit) {
+            if ((*sit)->isBad()) continue;
+            const size_t nIDj = (*sit)->mUniqueId;
+            if ((nIDi != pCurKF->mUniqueId || nIDj != pLoopKF->mUniqueId) && pKF->GetWeight(*sit) < minFeat) continue;
+            add_edge(nIDi, nIDj, vScw[nIDj] * Swi);
+            sInsertedEdges.insert(std::make_pair(std::min(nIDi, nIDj), std::max(nIDi, nIDj)));
+        }
+    }
+    // ---- spanning tree, earlier loop edges, strong covisibility edges (:1159-1250)
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        const kfptr pKF = vpKFs[i];
+        const size_t nIDi = pKF->mUniqueId;
+        const g2o::Sim3* nc = non_corrected(pKF);
+        const g2o::Sim3 Swi = nc ? nc->inverse() : vScw[nIDi].inverse();
+        auto Sxw = [&](const kfptr& k) -> g2o::Sim3 { const g2o::Sim3* n = non_corrected(k); return n ? *n : vScw[k->mUniqueId]; };
+        const kfptr pParentKF = pKF->GetParent();
+        if (pParentKF) add_edge(nIDi, pParentKF->mUniqueId, Sxw(pParentKF) * Swi);
+        const std::set<kfptr> sLoopEdges = pKF->GetLoopEdges();
+        for (std::set<kfptr>::const_iterator sit = sLoopEdges.begin(); sit != sLoopEdges.end(); ++sit) {
+            const size_t nIDj = (*sit)->mUniqueId;
+            if (nIDj < nIDi) add_edge(nIDi, nIDj, Sxw(*sit) * Swi);
+        }
+        const std::vector<kfptr> vpConnectedKFs = pKF->GetCovisiblesByWeight(minFeat);
+        for (std::vector<kfptr>::const_iterator vit = vpConnectedKFs.begin(); vit != vpConnectedKFs.end(); ++vit) {
+            const kfptr pKFn = *vit;
+            if (pKFn->isBad()) continue;
+            if (pKFn && pKFn != pParentKF && !pKF->hasChild(pKFn) && !sLoopEdges.count(pKFn)) {
+                const size_t nIDj = pKFn->mUniqueId;
+                if (nIDj < nIDi) {
+                    if (sInsertedEdges.count(std::make_pair(std::min(nIDi, nIDj), std::max(nIDi, nIDj)))) continue;
+                    add_edge(nIDi, nIDj, Sxw(pKFn) * Swi);
+                }
+            }
+        }
+    }
+    // ---- optimize(20), Levenberg with lambda 1e-16 (:1072-1076, :1253-1254)
+    ccm_essential_graph eg{};
+    eg.n_vertices = (int32_t)fixed.size(); eg.sim3 = sim3.data(); eg.fixed = fixed.data(); eg.fix_scale = bFixScale ? 1 : 0;
+    eg.n_edges = (int32_t)ei.size(); eg.edge_i = ei.data(); eg.edge_j = ej.data(); eg.measurement = meas.data(); eg.iterations = 20;
+    if (ccm_optimize_essential_graph(ccm_shim::ctx(), &eg)) throw estd::infrastructure_ex();
+    // ---- SE3 pose recovering. Sim3:[sR t;0 1] -> SE3:[R t/s;0 1] (:1256-1276)
+    for (size_t i = 0; i < vpKFs.size(); i++) {
+        const kfptr pKFi = vpKFs[i];
+        const int32_t vtx = vertex_of[pKFi->mUniqueId];
+        if (vtx < 0) continue;
+        const g2o::Sim3 CorrectedSiw = sim3_from8(&sim3[8 * (size_t)vtx]);
+        const Eigen::Matrix3d eigR = CorrectedSiw.rotation().toRotationMatrix();
+        Eigen::Vector3d eigt = CorrectedSiw.translation();
+        eigt *= (1. / CorrectedSiw.scale());
+        pKFi->SetPose(Converter::toCvSE3(eigR, eigt), true);
+    }
+    // ---- correct the map points through their reference keyframe (:1278-1330)
+    const int nMP = (int)vpMPs.size();
+    std::vector<double> pts((size_t)3 * std::max(nMP, 1), 0.0);
+    std::vector<int32_t> ref(std::max(nMP, 1), -1);
+    for (int i = 0; i < nMP; i++) {
+        const mpptr pMP = vpMPs[i];
+        if (pMP->isBad()) continue;
+        size_t nIDr;
+        if (map_fusion ? pMP->mCorrectedByKF_MM == pCurKF->mId : pMP->mCorrectedByKF_LC == pCurKF->mId)
+            nIDr = map_fusion ? pMP->mCorrectedReference_MM : pMP->mCorrectedReference_LC;
+        else nIDr = pMP->GetReferenceKeyFrame()->mUniqueId;
+        if (nIDr > nMaxKFid) continue;
+        ref[i] = vertex_of[nIDr];
+        const cv::Mat P3Dw = pMP->GetWorldPos();
+        for (int k = 0; k < 3; k++) pts[3 * (size_t)i + k] = P3Dw.at<float>(k);
+    }
+    if (ccm_correct_map_points(ccm_shim::ctx(), nMP, pts.data(), ref.data(), eg.n_vertices, sim3_before.data(), sim3.data()))
+        throw estd::infrastructure_ex();
+    for (int i = 0; i < nMP; i++) {
+        if (ref[i] < 0) continue;
+        const mpptr pMP = vpMPs[i];
+        pMP->SetWorldPos(Converter::toCvMat(Eigen::Matrix<double, 3, 1>(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2])), true);
+        pMP->UpdateNormalAndDepth();
+    }
+}
+}  // namespace
+
+void Optimizer::OptimizeEssentialGraphLoopClosure(mapptr pMap, kfptr pLoopKF, kfptr pCurKF, const KeyFrameAndPose& NonCorrectedSim3,
+                                                  const KeyFrameAndPose& CorrectedSim3, const map<kfptr, set<kfptr> >& LoopConnections,
+                                                  const bool& bFixScale)
+{
+    essential_graph(pMap, pLoopKF, pCurKF, &NonCorrectedSim3, &CorrectedSim3, LoopConnections, bFixScale, false);
+}
+
+void Optimizer::OptimizeEssentialGraphMapFusion(mapptr pMap, kfptr pLoopKF, kfptr pCurKF, const map<kfptr, set<kfptr> >& LoopConnections,
+                                                const bool& bFixScale)
+{
+    essential_graph(pMap, pLoopKF, pCurKF, nullptr, nullptr, LoopConnections, bFixScale, true);
 }
 
 }  // namespace cslam

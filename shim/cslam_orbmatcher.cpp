@@ -10,6 +10,7 @@
 #include <cslam/Frame.h>
 #include <cslam/KeyFrame.h>
 #include <cslam/MapPoint.h>
+#include <algorithm>
 #include <climits>
 #include <set>
 #include "ccm_shim.h"

@@ -100,7 +100,10 @@ def test_shim_sources_use_the_abi_as_declared():
     assert total >= 10
     used = set(re.findall(r"\b(ccm_\w+)\s*\(", "".join(_strip_comments(open(f).read()) for f in files)))
     for needed in ("ccm_orb_tables", "ccm_orb_extract", "ccm_descriptor_distance", "ccm_match_bow", "ccm_search_by_projection",
-                   "ccm_ba_solve", "ccm_pose_optimize", "ccm_pose_from_mat4f", "ccm_pose_to_mat4f", "ccm_create"):
+                   "ccm_ba_solve", "ccm_pose_optimize", "ccm_pose_from_mat4f", "ccm_pose_to_mat4f", "ccm_create",
+                   "ccm_fuse_select", "ccm_search_by_projection_frame", "ccm_search_by_projection_sim3", "ccm_search_for_initialization",
+                   "ccm_search_for_triangulation", "ccm_search_by_sim3", "ccm_optimize_sim3", "ccm_optimize_essential_graph",
+                   "ccm_correct_map_points"):
         assert needed in used, needed
 
 
@@ -121,7 +124,15 @@ def test_every_reference_signature_the_shim_defines_exists_in_the_reference_head
     for name in ("ORBextractor::operator()", "ORBextractor::ORBextractor", "ORBmatcher::DescriptorDistance", "ORBmatcher::SearchByBoW",
                  "ORBmatcher::SearchByProjection", "Optimizer::MapFusionGBA", "Optimizer::BundleAdjustmentClient",
                  "Optimizer::GlobalBundleAdjustemntClient", "Optimizer::PoseOptimizationClient", "Optimizer::LocalBundleAdjustmentClient",
-                 "ORBmatcher::Fuse(kfptr pKF, const std::vector<mpptr>& vpMapPoints", "ORBmatcher::Fuse(kfptr pKF, cv::Mat Scw"):
+                 "ORBmatcher::Fuse(kfptr pKF, const std::vector<mpptr>& vpMapPoints", "ORBmatcher::Fuse(kfptr pKF, cv::Mat Scw",
+                 # every public entry point of the two classes (include/cslam/ORBmatcher.h:89-158, include/cslam/Optimizer.h:84-113)
+                 "ORBmatcher::SearchByProjection(Frame& F, const std::vector<mpptr>& vpMapPoints",
+                 "ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame",
+                 "ORBmatcher::SearchByProjection(Frame& CurrentFrame, kfptr pKF, const std::set<mpptr>& sAlreadyFound",
+                 "ORBmatcher::SearchByProjection(kfptr pKF, cv::Mat Scw", "ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2",
+                 "ORBmatcher::SearchForTriangulation(kfptr pKF1, kfptr pKF2, cv::Mat F12", "ORBmatcher::SearchBySim3(kfptr pKF1, kfptr pKF2",
+                 "Optimizer::OptimizeSim3(kfptr pKF1, kfptr pKF2", "Optimizer::OptimizeEssentialGraphLoopClosure(mapptr pMap",
+                 "Optimizer::OptimizeEssentialGraphMapFusion(mapptr pMap"):
         assert name in src, name
 
 

@@ -868,7 +868,14 @@ __device__ __forceinline__ int oct_nonempty(const int* cc, int p)
 #ifndef OCT_WAVES
 #define OCT_WAVES 4             // measured: 1 -> 0.22 ms, 2 -> 0.41, 4 -> 0.135, 8 -> 0.23 ms per 256 frames
 #endif
-__global__ __launch_bounds__(64 * OCT_WAVES) void k_octree(const OrbGeom g, const OrbCell* __restrict__ cells,
+// (90 registers = 5 workgroups per CU for 2048 workgroups; forcing 6 / 8 with -DOCT_WPE (40 / 96 bytes of spills) measured no gain:
+//  step 1.064 / 1.071 / 1.083 ms at 5 / 6 / 8 -- the kernel is the chain inside a workgroup, not the second round of workgroups)
+#ifdef OCT_WPE
+#define OCT_OCC __attribute__((amdgpu_waves_per_eu(OCT_WPE, OCT_WPE)))
+#else
+#define OCT_OCC
+#endif
+__global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom g, const OrbCell* __restrict__ cells,
                                                const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
                                                unsigned* keysA, unsigned* keysB,
                                                unsigned* __restrict__ out, int* __restrict__ out_count,

@@ -868,6 +868,9 @@ __device__ __forceinline__ int oct_nonempty(const int* cc, int p)
 #ifndef OCT_WAVES
 #define OCT_WAVES 4             // measured: 1 -> 0.22 ms, 2 -> 0.41, 4 -> 0.135, 8 -> 0.23 ms per 256 frames
 #endif
+// (Round 3 also put the two key buffers into LDS for levels with <= 2048 candidates -- every level of the bench frames -- so that the
+//  passes below chain LDS instead of global round trips: 0.1208 ms against 0.1198 for this kernel, no gain; the passes are bound by
+//  their barriers and the list bookkeeping every wave repeats, not by where the keys live.  Not kept.)
 // (90 registers = 5 workgroups per CU for 2048 workgroups; forcing 6 / 8 with -DOCT_WPE (40 / 96 bytes of spills) measured no gain:
 //  step 1.064 / 1.071 / 1.083 ms at 5 / 6 / 8 -- the kernel is the chain inside a workgroup, not the second round of workgroups)
 #ifdef OCT_WPE

@@ -81,6 +81,10 @@ __device__ __forceinline__ int wave_sum(int v)
 // Fixed-point bilinear exactly as cv::resize(INTER_LINEAR) for 8-bit data:
 // weights are the host-made 11-bit tables, horizontal pass int32, vertical pass
 // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2 >> 2.
+// Round 3 built the streaming alternative -- a wave walks 32 output rows of its 256-column strip, loads every source row once (6 rows
+// requested ahead), keeps its horizontal pass for the two output rows that need it (3.6 instead of 6 loaded dwords per output row) --
+// bit-exact, and slower: 0.270 against 0.173 ms for the seven levels.  Its serial row loop needs selects, moves and address arithmetic
+// that the fully unrolled kernel below does not (18 against 14 vector instructions per pixel), and a quarter of the waves.  Not kept.
 #ifndef RS_ROWS
 #define RS_ROWS 8                // rows per thread (measured: 4 -> 0.186, 8 -> 0.172, 16 -> 0.260 ms)
 #endif

@@ -3,6 +3,7 @@ host-only entry points agree with the oracle.  No GPU work here."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -136,3 +137,15 @@ def test_library_links_no_dense_solver_library():
     assert needed and not [n for n in needed if "rocsolver" in n or "rocblas" in n], needed
     syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "rocsolver_" not in syms and "rocblas_" not in syms
+
+
+def test_landmark_cholesky_pivots(tmp_path):
+    """ba_math.h's Cholesky of a landmark's 3 x 3 block (operand of the Schur product): exact on a well-conditioned block, finite on
+    a rank-deficient one (a landmark with ONE observation) at dampings down to 0 -- ADVICE r2: an unguarded pivot gave NaN there."""
+    import re
+    exe = str(tmp_path / "chol3_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "support", "chol3_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    r = {k: float(v) for k, v in re.findall(r"(\w+)=([-+.\de]+)", out.stdout)}
+    assert r["spd_err"] < 1e-14 and r["rank_deficient_finite"] == 1, out.stdout

@@ -1344,6 +1344,7 @@ __device__ __forceinline__ void od_load_patch(const OdItem& it, int lane, unsign
         }
     }
 }
+template <int ITEMS>
 __global__ __launch_bounds__(64 * OD_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_orient_desc(const OrbGeom g, const unsigned* __restrict__ sel,
                                                      const int* __restrict__ sel_count,
                                                      ccm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
@@ -1360,7 +1361,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) __attribute__((amdgpu_waves_per_eu(8
     const int f = wy + g.frame0;
     // ---- this wave's slots, one per lane: slot -> (level, k); output row = keypoints of lower levels + k (level-major order, :1249-1276)
     const int* sc = sel_count + (long long)f * g.nlevels;
-    const int slot = (wx * OD_ITEMS + min(lane, OD_ITEMS - 1)) * OD_WAVES + wv;
+    const int slot = (wx * ITEMS + min(lane, ITEMS - 1)) * OD_WAVES + wv;
     const unsigned key_l = slot < g.out_per_frame ? sel[(long long)f * g.out_per_frame + slot] : 0u;     // (requested before the tables are built)
     // the 256 test pairs (x0, y0, x1, y1 as signed bytes): read from LDS per keypoint (as global loads they put a wait for ALL of the
     // wave's outstanding memory operations, the previous descriptor stores included, in front of each of the four rounds)
@@ -1383,7 +1384,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) __attribute__((amdgpu_waves_per_eu(8
         counts[f] = min(tot, max_per_image);
         if (tot > max_per_image) atomicOr(status, 8);
     }
-    const bool valid_l = lane < OD_ITEMS && slot < g.out_per_frame && slot - first_l < cnt_l && row_l < max_per_image;
+    const bool valid_l = lane < ITEMS && slot < g.out_per_frame && slot - first_l < cnt_l && row_l < max_per_image;
     unsigned long long todo = __ballot(valid_l);
     __syncthreads();                                                       // (the weight tables)
     if (todo == 0) return;
@@ -1570,6 +1571,12 @@ void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_fra
 {
     static const int xcd_on = getenv("CCM_ORB_XCD_OD") ? atoi(getenv("CCM_ORB_XCD_OD")) : (getenv("CCM_ORB_XCD") ? atoi(getenv("CCM_ORB_XCD")) : 1);
     static const size_t lds_pad = getenv("CCM_OD_LDS_PAD") ? (size_t)atol(getenv("CCM_OD_LDS_PAD")) : 0;     // occupancy experiment only
-    hipLaunchKernelGGL(k_orient_desc, dim3((out_per_frame + OD_WAVES * OD_ITEMS - 1) / (OD_WAVES * OD_ITEMS), nframes), dim3(64 * OD_WAVES), lds_pad, s,
-                       g_dev, sel, sel_count, kps, desc, counts, max_per_image, status, xcd_on);
+    // a wave per slot while that still fills the GPU only a few times over (a single frame is 1,032 waves: eight slots per wave would be
+    // 33 workgroups working through their slots one after the other), OD_ITEMS slots per wave for batches
+    if ((long long)out_per_frame * nframes < 4 * 8192)
+        hipLaunchKernelGGL(k_orient_desc<1>, dim3((out_per_frame + OD_WAVES - 1) / OD_WAVES, nframes), dim3(64 * OD_WAVES), lds_pad, s,
+                           g_dev, sel, sel_count, kps, desc, counts, max_per_image, status, xcd_on);
+    else
+        hipLaunchKernelGGL(k_orient_desc<OD_ITEMS>, dim3((out_per_frame + OD_WAVES * OD_ITEMS - 1) / (OD_WAVES * OD_ITEMS), nframes), dim3(64 * OD_WAVES), lds_pad, s,
+                           g_dev, sel, sel_count, kps, desc, counts, max_per_image, status, xcd_on);
 }

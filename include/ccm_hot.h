@@ -269,6 +269,15 @@ int ccm_search_by_sim3(ccm_ctx*, const ccm_frame_grid* kf1, const float* scale_f
 int ccm_search_by_projection_sim3(ccm_ctx*, const ccm_frame_grid* kf, const float* scale_factors, int n_mp, const uint8_t* valid,
                                   const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc, const uint8_t* observed,
                                   uint8_t* matched, float th, int32_t* best_idx);
+/* ccm_search_by_projection_sim3 for n_kf keyframes in ONE launch per kernel -- the loop closer projects the loop's map points into
+ * every keyframe connected to the current one (src/LoopFinder.cpp, src/MapMatcher.cpp: one SearchByProjection(pKF, Scw, vpPoints,
+ * vpMatched, th) per keyframe).  Keyframe k's map points are rows mp_first[k] .. mp_first[k+1]-1 (mp_first[0] = 0) of valid / u / v /
+ * level / mp_desc / observed / best_idx; its vpMatched flags are bytes F_k .. F_k + kfs[k].n - 1 of `matched` with F_k = kfs[0].n + ...
+ * + kfs[k-1].n (in/out); best_idx is an index into keyframe k's own features; n_matches[k] = what the single call returns for
+ * keyframe k.  Returns the sum, i.e. exactly what n_kf sequential calls return and write. */
+int ccm_search_by_projection_sim3_batch(ccm_ctx*, int n_kf, const ccm_frame_grid* kfs, const float* scale_factors, const int32_t* mp_first,
+                                        const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc,
+                                        const uint8_t* observed, uint8_t* matched, float th, int32_t* best_idx, int32_t* n_matches);
 
 /* ORBmatcher::SearchForTriangulation (ORBmatcher.cpp:700-852): per feature of KF1 without a map point, the most
  * similar (<= TH_LOW, last one among equals) feature of KF2 in the same vocabulary node that has no map point, is

@@ -290,12 +290,17 @@ struct GreedyArgs {
     int nq, n, cap; const int* ci; const int* cd; const int* cn; const uint8_t* active; const int* qlevel; const int* oct; const uint8_t* qflag;
     uint8_t* flag; float nnratio; int* out; int* status;
     int orb_dist, check_ori; const float* q_angle; const float* f_angle; int* ev;
+    const struct GreedyKf* kfs;
 };
+struct GreedyKf { int q0, nq, f0, n; };
+int match_launch_window_greedy_batch(hipStream_t, const GreedyArgs&, int n_kf, int max_n);
+void match_launch_window_batch(hipStream_t, const WinGrid* grids, const int* q_kf, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
+                               const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn);
 size_t match_window_greedy_lds(int n, int nq);
 int match_launch_window_greedy(hipStream_t, int mode, const GreedyArgs&);
 
 struct WindowBufs { DevBuf kx, ky, oct, desc, cfirst, citems, qx, qy, qr, minl, maxl, qdesc, ci, cd, cn, sel_i, sel_d, is2, act, qlvl, qflag, flag, out, status, qang, fang, ev,
-                           grids, qkf; };
+                           grids, qkf, gkf; };
 // LDS the single-workgroup acceptance kernel may ask for (claim + flag per feature, one byte per query); larger problems take the
 // host loops below
 static const size_t kGreedyLdsMax = 150 * 1024;
@@ -393,7 +398,7 @@ static int window_greedy(ccm_ctx* c, const ccm_frame_grid* f, int nq, const floa
         CCM_HIP(c, hipMemsetAsync(W.out.p, 0xFF, (size_t)n_out * 4, st));
         GreedyArgs A{ nq, f->n, cap, W.ci.as<int>(), W.cd.as<int>(), W.cn.as<int>(), W.act.as<uint8_t>(), qlevel ? W.qlvl.as<int>() : nullptr,
                       W.oct.as<int>(), W.qflag.as<uint8_t>(), W.flag.as<uint8_t>(), nnratio, W.out.as<int>(), W.status.as<int>(),
-                      orb_dist, check_ori, W.qang.as<float>(), W.fang.as<float>(), W.ev.as<int>() };
+                      orb_dist, check_ori, W.qang.as<float>(), W.fang.as<float>(), W.ev.as<int>(), nullptr };
         if (match_launch_window_greedy(st, mode, A)) return ccm_fail(c, CCM_E_DEVICE, "k_window_greedy: LDS request refused");
         CCM_HIP(c, hipGetLastError());
         int status[3] = { 0, 0, 0 };
@@ -412,7 +417,7 @@ void match_window_free(WindowBufs* w)
 {
     if (!w) return;
     DevBuf* all[] = { &w->kx, &w->ky, &w->oct, &w->desc, &w->cfirst, &w->citems, &w->qx, &w->qy, &w->qr, &w->minl, &w->maxl, &w->qdesc, &w->ci, &w->cd, &w->cn,
-                      &w->sel_i, &w->sel_d, &w->is2, &w->act, &w->qlvl, &w->qflag, &w->flag, &w->out, &w->status, &w->qang, &w->fang, &w->ev, &w->grids, &w->qkf };
+                      &w->sel_i, &w->sel_d, &w->is2, &w->act, &w->qlvl, &w->qflag, &w->flag, &w->out, &w->status, &w->qang, &w->fang, &w->ev, &w->grids, &w->qkf, &w->gkf };
     for (DevBuf* b : all) b->release();
     delete w;
 }
@@ -821,6 +826,124 @@ int ccm_search_by_projection_sim3(ccm_ctx* c, const ccm_frame_grid* kf, const fl
         }
     }
     return nmatches;
+}
+
+// ccm_search_by_projection_sim3 for n_kf keyframes in ONE launch of each kernel (the loop closer matches the loop points into every
+// keyframe connected to the current one, src/LoopFinder.cpp / MapMatcher.cpp: one SearchByProjection(pKF, Scw, ...) per keyframe).
+// Keyframes are independent problems -- each has its own vpMatched -- so workgroup k of k_window_greedy takes keyframe k.
+int ccm_search_by_projection_sim3_batch(ccm_ctx* c, int n_kf, const ccm_frame_grid* kfs, const float* scale_factors, const int32_t* mp_first,
+                                        const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* mp_desc,
+                                        const uint8_t* observed, uint8_t* matched, float th, int32_t* best_idx, int32_t* n_matches)
+{
+    if (!c) return CCM_E_ARG;
+    if (n_kf < 0 || (n_kf > 0 && (!kfs || !mp_first || !n_matches))) return ccm_fail(c, CCM_E_ARG, "bad SearchByProjection(kf, Scw) batch arguments");
+    if (n_kf == 0) return 0;
+    const int n_mp = mp_first[n_kf];
+    if (mp_first[0] != 0 || n_mp < 0 || (n_mp > 0 && (!valid || !u || !v || !level || !mp_desc || !observed || !best_idx || !scale_factors)))
+        return ccm_fail(c, CCM_E_ARG, "bad SearchByProjection(kf, Scw) batch arguments");
+    std::vector<int> feat_first(n_kf + 1, 0), cell_first_off(n_kf + 1, 0);
+    int max_n = 0;
+    for (int k = 0; k < n_kf; k++) {
+        if (mp_first[k + 1] < mp_first[k] || kfs[k].n < 0 || kfs[k].grid_cols < 1 || kfs[k].grid_rows < 1)
+            return ccm_fail(c, CCM_E_ARG, "bad SearchByProjection(kf, Scw) batch arguments");
+        feat_first[k + 1] = feat_first[k] + kfs[k].n; cell_first_off[k + 1] = cell_first_off[k] + kfs[k].grid_cols * kfs[k].grid_rows + 1;
+        max_n = std::max(max_n, kfs[k].n);
+        n_matches[k] = 0;
+    }
+    const int NF = feat_first[n_kf];
+    if (NF > 0 && !matched) return ccm_fail(c, CCM_E_ARG, "bad SearchByProjection(kf, Scw) batch arguments");
+    for (int m = 0; m < n_mp; m++) best_idx[m] = -1;
+    if (n_mp == 0 || NF == 0) return 0;
+    static const bool host_accept = getenv("CCM_WINDOW_HOST_ACCEPT") && atoi(getenv("CCM_WINDOW_HOST_ACCEPT")) != 0;   // test switch
+    if (host_accept || match_window_greedy_lds(max_n, 0) > kGreedyLdsMax) {          // keyframe by keyframe through the single entry point
+        int total = 0;
+        for (int k = 0; k < n_kf; k++) {
+            const int q0 = mp_first[k], nq = mp_first[k + 1] - q0;
+            const int r = ccm_search_by_projection_sim3(c, &kfs[k], scale_factors, nq, valid + q0, u + q0, v + q0, level + q0, mp_desc + (size_t)q0 * 32,
+                                                        observed + q0, matched + feat_first[k], th, best_idx + q0);
+            if (r < 0) return r;
+            n_matches[k] = r; total += r;
+        }
+        return total;
+    }
+    CCM_HIP(c, hipSetDevice(c->device));
+    if (!c->match) c->match = new MatchState();
+    if (!c->match->win) c->match->win = new WindowBufs();
+    WindowBufs& W = *c->match->win;
+    // per keyframe: Frame::AssignFeaturesToGrid (as window_run), everything concatenated; a keyframe's items index its own features
+    std::vector<float> kx(NF), ky(NF), qr(n_mp);
+    std::vector<int32_t> oct(NF), items(NF), cfirst(cell_first_off[n_kf]), none(n_mp, -1), qkf(n_mp);
+    std::vector<uint8_t> fdesc((size_t)NF * 32);
+    std::vector<GreedyKf> gk(n_kf);
+    for (int k = 0; k < n_kf; k++) {
+        const ccm_frame_grid& f = kfs[k];
+        const int n = f.n, cells = f.grid_cols * f.grid_rows, f0 = feat_first[k];
+        int* first = cfirst.data() + cell_first_off[k];
+        std::vector<int> cell(n);
+        for (int q = 0; q <= cells; q++) first[q] = 0;
+        for (int i = 0; i < n; i++) {
+            const int px = (int)std::round((f.kp_x[i] - f.min_x) * f.inv_w), py = (int)std::round((f.kp_y[i] - f.min_y) * f.inv_h);
+            cell[i] = (px < 0 || px >= f.grid_cols || py < 0 || py >= f.grid_rows) ? -1 : px * f.grid_rows + py;
+            if (cell[i] >= 0) first[cell[i] + 1]++;
+            kx[f0 + i] = f.kp_x[i]; ky[f0 + i] = f.kp_y[i]; oct[f0 + i] = f.kp_octave[i];
+        }
+        if (n) memcpy(fdesc.data() + (size_t)f0 * 32, f.desc, (size_t)n * 32);
+        for (int q = 0; q < cells; q++) first[q + 1] += first[q];
+        { std::vector<int> fill(first, first + cells); for (int i = 0; i < n; i++) if (cell[i] >= 0) items[f0 + fill[cell[i]]++] = i; }
+        for (int m = mp_first[k]; m < mp_first[k + 1]; m++) {
+            qkf[m] = k;
+            qr[m] = (valid[m] && n > 0) ? th * scale_factors[level[m]] : -1.f;                    // :380
+        }
+        gk[k] = GreedyKf{ mp_first[k], mp_first[k + 1] - mp_first[k], f0, n };
+    }
+    hipStream_t st = c->stream;
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        CCM_RESERVE(c, b, std::max<size_t>(bytes, 16));
+        if (bytes) CCM_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+        return CCM_OK;
+    };
+    int rc;
+    if ((rc = up(W.kx, kx.data(), (size_t)NF * 4)) || (rc = up(W.ky, ky.data(), (size_t)NF * 4)) || (rc = up(W.oct, oct.data(), (size_t)NF * 4)) ||
+        (rc = up(W.desc, fdesc.data(), (size_t)NF * 32)) || (rc = up(W.cfirst, cfirst.data(), cfirst.size() * 4)) || (rc = up(W.citems, items.data(), (size_t)NF * 4)) ||
+        (rc = up(W.qx, u, (size_t)n_mp * 4)) || (rc = up(W.qy, v, (size_t)n_mp * 4)) || (rc = up(W.qr, qr.data(), (size_t)n_mp * 4)) ||
+        (rc = up(W.minl, none.data(), (size_t)n_mp * 4)) || (rc = up(W.maxl, none.data(), (size_t)n_mp * 4)) || (rc = up(W.qdesc, mp_desc, (size_t)n_mp * 32)) ||
+        (rc = up(W.qkf, qkf.data(), (size_t)n_mp * 4)) || (rc = up(W.act, valid, (size_t)n_mp)) || (rc = up(W.qflag, observed, (size_t)n_mp)) ||
+        (rc = up(W.qlvl, level, (size_t)n_mp * 4)) || (rc = up(W.gkf, gk.data(), gk.size() * sizeof(GreedyKf))))
+        return rc;
+    std::vector<WinGrid> grids(n_kf);
+    for (int k = 0; k < n_kf; k++) {
+        const ccm_frame_grid& f = kfs[k];
+        grids[k] = WinGrid{ f.n, f.grid_cols, f.grid_rows, f.min_x, f.min_y, f.inv_w, f.inv_h, W.kx.as<float>() + feat_first[k], W.ky.as<float>() + feat_first[k],
+                            W.oct.as<int>() + feat_first[k], W.desc.as<uint8_t>() + (size_t)feat_first[k] * 32, W.cfirst.as<int>() + cell_first_off[k],
+                            W.citems.as<int>() + feat_first[k] };
+    }
+    if ((rc = up(W.grids, grids.data(), grids.size() * sizeof(WinGrid)))) return rc;
+    CCM_RESERVE(c, W.out, (size_t)n_mp * 4); CCM_RESERVE(c, W.status, (size_t)n_kf * 12 + 16); CCM_RESERVE(c, W.cn, (size_t)n_mp * 4);
+    std::vector<int> status(3 * (size_t)n_kf);
+    int cap = 64;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        CCM_RESERVE(c, W.ci, (size_t)n_mp * cap * 4); CCM_RESERVE(c, W.cd, (size_t)n_mp * cap * 4);
+        if ((rc = up(W.flag, matched, (size_t)NF))) return rc;                // (again on a retry: the first attempt may have set flags)
+        match_launch_window_batch(st, W.grids.as<WinGrid>(), W.qkf.as<int>(), n_mp, W.qx.as<float>(), W.qy.as<float>(), W.qr.as<float>(), W.minl.as<int>(),
+                                  W.maxl.as<int>(), W.qdesc.as<uint8_t>(), cap, W.ci.as<int>(), W.cd.as<int>(), W.cn.as<int>());
+        CCM_HIP(c, hipMemsetAsync(W.out.p, 0xFF, (size_t)n_mp * 4, st));
+        GreedyArgs A{ 0, 0, cap, W.ci.as<int>(), W.cd.as<int>(), W.cn.as<int>(), W.act.as<uint8_t>(), W.qlvl.as<int>(), W.oct.as<int>(), W.qflag.as<uint8_t>(),
+                      W.flag.as<uint8_t>(), 0.f, W.out.as<int>(), W.status.as<int>(), 0, 0, nullptr, nullptr, nullptr, W.gkf.as<GreedyKf>() };
+        if (match_launch_window_greedy_batch(st, A, n_kf, max_n)) return ccm_fail(c, CCM_E_DEVICE, "k_window_greedy: LDS request refused");
+        CCM_HIP(c, hipGetLastError());
+        CCM_HIP(c, hipMemcpyAsync(status.data(), W.status.p, status.size() * 4, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        int need = 0;
+        for (int k = 0; k < n_kf; k++) if (status[3 * k] < 0) need = std::max(need, status[3 * k + 1]);
+        if (need > 0) { cap = need; continue; }                               // rare: a denser window than expected (in any keyframe: all repeat)
+        CCM_HIP(c, hipMemcpyAsync(best_idx, W.out.p, (size_t)n_mp * 4, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipMemcpyAsync(matched, W.flag.p, (size_t)NF, hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        int total = 0;
+        for (int k = 0; k < n_kf; k++) { n_matches[k] = status[3 * k]; total += status[3 * k]; }
+        return total;
+    }
+    return ccm_fail(c, CCM_E_CAPACITY, "window candidate lists keep overflowing");
 }
 
 // ORBmatcher::CheckDistEpipolarLine, ORBmatcher.cpp:159-176

@@ -469,13 +469,17 @@ struct WinGrid {
     const float* kx; const float* ky; const int* oct; const uint8_t* desc;
     const int* cell_first; const int* cell_items;
 };
-__global__ __launch_bounds__(256) void k_window_candidates(WinGrid G, int nq, const float* __restrict__ qx, const float* __restrict__ qy,
+// BATCH: the queries of many keyframes in one launch, query q against grids[q_kf[q]]; the candidate indices are the keyframe's own.
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_window_candidates(WinGrid G1, const WinGrid* __restrict__ grids, const int* __restrict__ q_kf,
+                                                           int nq, const float* __restrict__ qx, const float* __restrict__ qy,
                                                            const float* __restrict__ qr, const int* __restrict__ min_level,
                                                            const int* __restrict__ max_level, const uint8_t* __restrict__ qdesc, int cap,
                                                            int* __restrict__ cand_idx, int* __restrict__ cand_dist, int* __restrict__ cand_n)
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq) return;
+    const WinGrid G = BATCH ? grids[q_kf[q]] : G1;
     const float x = qx[q], y = qy[q], r = qr[q];
     const int minL = min_level[q], maxL = max_level[q];
     int n = 0;
@@ -626,12 +630,23 @@ struct GreedyArgs {
     int* status;                                      // [0] matches (or -1: a list overflowed), [1] longest list, [2] most rounds a wave needed
     // MODE 2: acceptance threshold, rotation check and its inputs; ev[point] = accepted feature << 8 | rotation bin (or -1)
     int orb_dist, check_ori; const float* q_angle; const float* f_angle; int* ev;
+    // batch (MODE 1, ccm_search_by_projection_sim3_batch): workgroup k works on keyframe k -- queries kfs[k].q0 .. +nq of the per-query
+    // arrays, features kfs[k].f0 .. +n of the per-feature arrays, status words 3k .. 3k+2; nullptr = one problem, as described above
+    const struct GreedyKf* kfs;
 };
+struct GreedyKf { int q0, nq, f0, n; };
 #define WG_REG_CAND 16
 #define WG_BATCH_ROUNDS 3
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
 {
+    if (A.kfs) {
+        const GreedyKf k = A.kfs[blockIdx.x];
+        A.ci += (long long)k.q0 * A.cap; A.cd += (long long)k.q0 * A.cap; A.cn += k.q0; A.active += k.q0; A.qflag += k.q0;
+        if (A.qlevel) A.qlevel += k.q0;
+        A.oct += k.f0; A.flag += k.f0; A.out += MODE == 1 ? k.q0 : k.f0; A.status += 3 * blockIdx.x;
+        A.nq = k.nq; A.n = k.n;
+    }
     extern __shared__ int wg_lds[];
     int* claim = wg_lds;                                            // [n]
     uint8_t* flag = reinterpret_cast<uint8_t*>(claim + A.n);        // [n]
@@ -812,6 +827,13 @@ __global__ __launch_bounds__(1024) void k_window_greedy(GreedyArgs A)
     if (tid == 0) { A.status[0] = s_count; A.status[1] = s_maxcn; A.status[2] = s_rounds; }
 }
 size_t match_window_greedy_lds(int n, int nq) { (void)nq; return (size_t)4 * n + 2 * (size_t)((n + 3) & ~3) + 16; }
+int match_launch_window_greedy_batch(hipStream_t s, const GreedyArgs& A, int n_kf, int max_n)
+{
+    const size_t lds = match_window_greedy_lds(max_n, 0);
+    if (hipFuncSetAttribute((const void*)k_window_greedy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_window_greedy<1>, dim3(n_kf), dim3(1024), lds, s, A);
+    return 0;
+}
 int match_launch_window_greedy(hipStream_t s, int mode, const GreedyArgs& A)
 {
     const size_t lds = match_window_greedy_lds(A.n, A.nq);
@@ -831,7 +853,13 @@ int match_launch_window_greedy(hipStream_t s, int mode, const GreedyArgs& A)
 void match_launch_window(hipStream_t s, const WinGrid& G, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
                          const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn)
 {
-    hipLaunchKernelGGL(k_window_candidates, dim3((nq + 3) / 4), dim3(256), 0, s, G, nq, qx, qy, qr, minl, maxl, qdesc, cap, ci, cd, cn);
+    hipLaunchKernelGGL(k_window_candidates<false>, dim3((nq + 3) / 4), dim3(256), 0, s, G, (const WinGrid*)nullptr, (const int*)nullptr, nq, qx, qy, qr, minl, maxl, qdesc, cap,
+                       ci, cd, cn);
+}
+void match_launch_window_batch(hipStream_t s, const WinGrid* grids, const int* q_kf, int nq, const float* qx, const float* qy, const float* qr, const int* minl,
+                               const int* maxl, const uint8_t* qdesc, int cap, int* ci, int* cd, int* cn)
+{
+    if (nq > 0) hipLaunchKernelGGL(k_window_candidates<true>, dim3((nq + 3) / 4), dim3(256), 0, s, WinGrid{}, grids, q_kf, nq, qx, qy, qr, minl, maxl, qdesc, cap, ci, cd, cn);
 }
 
 // variant: 0 = 512 threads x 2 queries, 1 = 256 x 4, 2 = 1024 x 1 (tuning knob, CCM_BF_VARIANT)

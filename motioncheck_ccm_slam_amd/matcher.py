@@ -233,6 +233,37 @@ def _search_by_projection_sim3(self, kf: FrameGridView, scale_factors, valid, u,
     return n, bi[:len(va)], mt
 
 
+def _search_by_projection_sim3_batch(self, kfs, scale_factors, per_kf, th: float):
+    """SearchByProjection(pKF, Scw, ...) for many keyframes in one launch per kernel (ccm_search_by_projection_sim3_batch).
+    kfs: list of FrameGridView; per_kf: list of (valid, u, v, level, mp_desc, observed, matched) per keyframe.
+    Returns a list of (nmatches, best_idx, matched after the call) per keyframe -- what SearchByProjectionSim3 returns keyframe by keyframe."""
+    a = np.ascontiguousarray
+    sf = a(scale_factors, "f4")
+    K = len(kfs)
+    first = np.zeros(K + 1, "i4"); ffirst = np.zeros(K + 1, "i8")
+    for k, t in enumerate(per_kf):
+        first[k + 1] = first[k] + len(t[0]); ffirst[k + 1] = ffirst[k] + len(kfs[k].kx)
+    cat = lambda i, dt: a(np.concatenate([np.asarray(t[i]) for t in per_kf]) if K else np.zeros(0), dt)
+    va, uu, vv, lv, ob = cat(0, np.uint8), cat(1, "f4"), cat(2, "f4"), cat(3, "i4"), cat(5, np.uint8)
+    md = a(np.concatenate([np.asarray(t[4], np.uint8).reshape(-1, 32) for t in per_kf]) if K else np.zeros((0, 32)), np.uint8)
+    mt = cat(6, np.uint8).copy()
+    assert len(mt) == ffirst[-1]
+    n = int(first[-1])
+    bi = np.full(max(n, 1), -1, "i4"); nm = np.zeros(max(K, 1), "i4")
+    if len(mt) == 0:
+        mt = np.zeros(1, np.uint8)
+    grids = (_lib.FrameGrid * max(K, 1))(*[kf.struct() for kf in kfs])
+    p = _lib.ptr
+    tot = self.ctx.check(self.lib.ccm_search_by_projection_sim3_batch(self.ctx.handle, K, C.cast(grids, C.c_void_p), p(sf), p(first), p(va), p(uu), p(vv), p(lv),
+                                                                      p(md), p(ob), p(mt), C.c_float(th), p(bi), p(nm)))
+    out = [(int(nm[k]), bi[first[k]:first[k + 1]].copy(), mt[ffirst[k]:ffirst[k + 1]].copy()) for k in range(K)]
+    assert tot == sum(o[0] for o in out)
+    return out
+
+
+ORBmatcher.SearchByProjectionSim3Batch = _search_by_projection_sim3_batch
+
+
 def _search_for_triangulation(self, desc1, node1, has_mp1, x1, y1, angle1, desc2, node2, has_mp2, x2, y2, angle2, octave2, F12, ex, ey,
                               scale_factors2, level_sigma2_2):
     """ORBmatcher::SearchForTriangulation (ORBmatcher.cpp:700-852).  Returns (nmatches, match12)."""

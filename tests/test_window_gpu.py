@@ -226,6 +226,43 @@ def test_search_by_projection_sim3(ctx, oracle):
         assert n > 200 and (mt.sum() - matched.sum()) == n
 
 
+def test_search_by_projection_sim3_batch_equals_keyframe_by_keyframe(ctx, oracle):
+    """ccm_search_by_projection_sim3_batch (round 3): the order-dependent acceptance (k_window_greedy) for K keyframes in one launch,
+    one workgroup per keyframe, against K sequential calls and the oracle; a keyframe without features and one without map points
+    ride along, and one keyframe has far more points than features (many points competing for a feature: the wave-by-wave rounds)."""
+    rng = np.random.default_rng(31)
+    kfs, per_kf = [], []
+    sf = None
+    for k, (seed, n_rel, n_rand) in enumerate(((4, 1400, 200), (5, 0, 0), (6, 6000, 500), (7, 300, 50), (9, 900, 0))):
+        fr, sf, kps, desc = _frame(ctx, seed)
+        nm = n_rel + n_rand
+        if nm:
+            mp_desc, u, v, level, src = _noisy_points(fr, desc, rng, n_rel, n_rand)
+        else:
+            mp_desc, u, v, level = np.zeros((0, 32), np.uint8), np.zeros(0, "f4"), np.zeros(0, "f4"), np.zeros(0, "i4")
+        valid = rng.random(nm) < 0.9
+        observed = rng.random(nm) < 0.15
+        matched = rng.random(len(fr.kx)) < 0.2
+        kfs.append(fr); per_kf.append((valid, u, v, level, mp_desc, observed, matched))
+    empty = FrameGridView(np.zeros(0, "f4"), np.zeros(0, "f4"), np.zeros(0, "i4"), np.zeros((0, 32), np.uint8))
+    kfs.insert(3, empty)
+    per_kf.insert(3, (np.ones(25, bool), rng.uniform(0, 752, 25).astype("f4"), rng.uniform(0, 480, 25).astype("f4"), rng.integers(0, 8, 25).astype("i4"),
+                      rng.integers(0, 256, (25, 32), dtype=np.uint8), np.zeros(25, bool), np.zeros(0, bool)))
+    m = ORBmatcher(ctx=ctx)
+    for th in (10.0, 4.0):
+        got = m.SearchByProjectionSim3Batch(kfs, sf, per_kf, th)
+        assert len(got) == len(kfs)
+        for k, (fr, t) in enumerate(zip(kfs, per_kf)):
+            n, bi, mt = m.SearchByProjectionSim3(fr, sf, *t, th)
+            assert got[k][0] == n and (got[k][1] == bi).all() and (got[k][2] == mt[:len(fr.kx)]).all(), k
+            if len(fr.kx) and len(t[0]):
+                rn, rbi, rmt = oracle.search_by_projection_sim3(fr, sf, *t, th)
+                assert got[k][0] == rn and (got[k][1] == rbi).all() and (got[k][2] == rmt).all(), k
+            else:
+                assert got[k][0] == 0 and (got[k][1] == -1).all()
+        assert sum(g[0] for g in got) > 1000
+
+
 def test_search_by_projection_keyframe_overload(ctx, oracle):
     """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): has_obs all ones, ORBdist 64."""
     fr, sf, kps, desc = _frame(ctx, 8)

@@ -90,6 +90,14 @@ t_bat = timed(lambda: m.FuseSelectBatch(kfs, sf, is2, per_kf, 3.0, True))
 t_cpu = timed(lambda: [O.fuse_select(fr.kx, fr.ky, fr.oct, desc, fr.min_x, fr.min_y, fr.inv_w, fr.inv_h, sf, is2, *per_kf[k], 3.0, True) for k in range(K)], 2)
 out["F1_fuse_select_20_keyframes"] = {"keyframes": K, "map_points_per_keyframe": nm, "sequential_calls_ms": round(t_seq * 1e3, 3), "one_batched_call_ms": round(t_bat * 1e3, 3),
                                       "cpu_oracle_ms": round(t_cpu * 1e3, 1)}
+# the loop closer's SearchByProjection(pKF, Scw, ...) over the keyframes connected to the current one: 20 keyframes x 1000 loop points,
+# keyframe by keyframe and in one launch per kernel (ccm_search_by_projection_sim3_batch, round 3)
+per_kf2 = [t + ((rng.random(nm) < 0.1).astype(np.uint8), (rng.random(n) < 0.1).astype(np.uint8)) for t in per_kf]
+t_seq = timed(lambda: [m.SearchByProjectionSim3(kfs[k], sf, *per_kf2[k], 8.0) for k in range(K)])
+t_bat = timed(lambda: m.SearchByProjectionSim3Batch(kfs, sf, per_kf2, 8.0))
+t_cpu = timed(lambda: [O.search_by_projection_sim3(fr, sf, *per_kf2[k], 8.0) for k in range(K)], 2)
+out["F1_search_by_projection_sim3_20_keyframes"] = {"keyframes": K, "map_points_per_keyframe": nm, "sequential_calls_ms": round(t_seq * 1e3, 3),
+                                                    "one_batched_call_ms": round(t_bat * 1e3, 3), "cpu_oracle_ms": round(t_cpu * 1e3, 1)}
 t_gpu = timed(lambda: m.SearchByProjectionSim3(fr, sf, valid, px, py, lvl, mp_desc, observed, matched, 8.0))
 t_cpu = timed(lambda: O.search_by_projection_sim3(fr, sf, valid, px, py, lvl, mp_desc, observed, matched, 8.0), 2)
 os.environ["CCM_WINDOW_HOST_ACCEPT"] = "1"      # read once per process by the library: the host-acceptance figure comes from a child process

@@ -95,6 +95,7 @@ struct BaState {
     hipStream_t side = nullptr;            // coarse-level inversion, concurrent with the PCG of the current trial
     hipEvent_t ev_hb = nullptr;            // the side stream has finished reading the reduced system
     hipEvent_t ev_inv = nullptr;           // the side stream has finished an inversion
+    hipEvent_t ev_up = nullptr;            // the side stream has finished uploading observations, information values and points
     hipEvent_t ev_copy = nullptr;          // the main stream has copied the last inverse out of the side stream's work matrix
     std::vector<hipEvent_t> clock_ev;      // phase timers of large problems (events instead of stream synchronisations)
     double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
@@ -110,6 +111,7 @@ void ba_state_free(BaState* s)
     if (s->side) (void)hipStreamSynchronize(s->side);
     if (s->ev_hb) (void)hipEventDestroy(s->ev_hb);
     if (s->ev_inv) (void)hipEventDestroy(s->ev_inv);
+    if (s->ev_up) (void)hipEventDestroy(s->ev_up);
     if (s->ev_copy) (void)hipEventDestroy(s->ev_copy);
     for (hipEvent_t e : s->clock_ev) (void)hipEventDestroy(e);
     if (s->pinned) (void)hipHostFree(s->pinned);
@@ -409,9 +411,28 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     if ((rc = upload(c, S.poses, pb->poses, 7 * (size_t)P))) return rc;
     if ((rc = upload(c, S.intr, pb->intr, 4 * (size_t)P))) return rc;
     if ((rc = upload(c, S.pose_of_free, pose_of_free.data(), nfree))) return rc;
-    if ((rc = upload(c, S.points, pb->points + 3 * (size_t)l0, 3 * (size_t)L))) return rc;
-    if ((rc = upload(c, S.obs, e_obs, 2 * (size_t)E))) return rc;
-    if ((rc = upload(c, S.info, e_info, E))) return rc;
+    // Large maps taken where they lie: observations, information values and points (48 of the 65 MB at config 5) are not needed
+    // before the first linearisation, so they go up on the context's first auxiliary stream while this stream builds the block
+    // structure of the reduced system from the index arrays (pair enumeration, radix sorts: 0.9 ms at config 5).
+    static const bool split_off = getenv("CCM_BA_SPLIT_UPLOAD") && atoi(getenv("CCM_BA_SPLIT_UPLOAD")) == 0;
+    const bool split_up = direct && ranks == 1 && Eall >= 400000 && nfree > 0 && !split_off;
+    if (split_up) {
+        hipStream_t up_st = ccm_aux_stream(c, 0);               // (the stream the coarse inversion uses later in the call: S.side)
+        if (!up_st) return ccm_fail(c, CCM_E_DEVICE, "hipStreamCreate failed");
+        if (!S.ev_up) CCM_HIP(c, hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
+        CCM_RESERVE(c, S.points, std::max<size_t>(3 * (size_t)L * 8, 16)); CCM_RESERVE(c, S.obs, std::max<size_t>(2 * (size_t)E * 8, 16));
+        CCM_RESERVE(c, S.info, std::max<size_t>((size_t)E * 8, 16));
+        if (L) CCM_HIP(c, hipMemcpyAsync(S.points.p, pb->points + 3 * (size_t)l0, 3 * (size_t)L * 8, hipMemcpyHostToDevice, up_st));
+        if (E) CCM_HIP(c, hipMemcpyAsync(S.obs.p, e_obs, 2 * (size_t)E * 8, hipMemcpyHostToDevice, up_st));
+        if (E) CCM_HIP(c, hipMemcpyAsync(S.info.p, e_info, (size_t)E * 8, hipMemcpyHostToDevice, up_st));
+        CCM_HIP(c, hipEventRecord(S.ev_up, up_st));
+    } else {
+        if ((rc = upload(c, S.points, pb->points + 3 * (size_t)l0, 3 * (size_t)L))) return rc;
+        if ((rc = upload(c, S.obs, e_obs, 2 * (size_t)E))) return rc;
+        if ((rc = upload(c, S.info, e_info, E))) return rc;
+    }
+    // whatever way this function is left, the copies out of the caller's arrays have finished by then
+    struct UploadDone { hipEvent_t e; ~UploadDone() { if (e) (void)hipEventSynchronize(e); } } upload_done{ split_up ? S.ev_up : nullptr };
     if (!dev_indexed) {                                        // (the device path has these already)
         if ((rc = upload(c, S.free_of, free_of.data(), P))) return rc;
         if ((rc = upload(c, S.edge_pose, e_pose, E))) return rc;
@@ -630,6 +651,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         } else (void)hipGetLastError();
     }
     lap("PCG graph capture");
+    if (split_up) CCM_HIP(c, hipStreamWaitEvent(st, S.ev_up, 0));          // observations, information values, points have arrived
     bool hb_in_use = false;                                // the side stream is still reading this trial's reduced system
     bool coarse_ready = false, coarse_pending = false;     // an inverse is in Aci / an inversion is running on the side stream
     bool copy_recorded = false;                            // ev_copy has been recorded in this call
@@ -959,6 +981,8 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     // ---- results
     CCM_HIP(c, hipMemcpyAsync(pb->poses, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToHost, st));
     if (ranks == 1) {
+        // (a page-locked landing area + a threaded copy for pageable destinations was measured: 1.19 against 0.75 ms for config 5's 4.8 MB --
+        //  the first touch of a freshly allocated destination costs the same either way, and the threads cost their creation)
         if (L) CCM_HIP(c, hipMemcpyAsync(pb->points, D.points, 3 * (size_t)L * 8, hipMemcpyDeviceToHost, st));
     } else {
         // every rank fills its landmark range of a zeroed full-size buffer; a sum all-reduce is the all-gather

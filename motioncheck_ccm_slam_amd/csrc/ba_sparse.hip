@@ -1627,8 +1627,10 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
 #pragma unroll
                 for (int k = 0; k < c; k++) d -= T[c][k] * T[c][k];
                 if (!(d > 0.0)) { s_bad = 1; d = 1.0; }
-                d = sqrt(d); T[c][c] = d;
-                const double id = 1.0 / d;
+                // 1 / sqrt(d) once, sqrt(d) = d / sqrt(d): a square root AND a division per pivot were two ~25-instruction sequences on the
+                // one thread every other thread waits for (a third of the kernel)
+                const double id = rsqrt(d);
+                T[c][c] = d * id;
                 dinv[c] = id;
 #pragma unroll
                 for (int r = c + 1; r < 6; r++) {

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from motioncheck_ccm_slam_amd import _lib, synth
 from motioncheck_ccm_slam_amd.optimizer import Optimizer

@@ -53,7 +53,7 @@ void sp_launch_bschur(hipStream_t, const BaDev&, double* bs);
 void sp_launch_add_lambda(hipStream_t, const int* diag, int nfree, double lambda, double* Hb);
 void sp_launch_to_dense(hipStream_t, const double* Hb, const int* br, const int* bc, int nb, long long n, double* Hs);
 int dense_small_max();
-int dense_launch_small_solve(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int n, const double* b, double* x, int* bad);
+int dense_launch_small_solve(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int n, const double* b, double* x, int* bad, double lambda);
 size_t pcg_minv_bytes(int nfree);
 hipError_t pcg_launch_minv(hipStream_t, const double* Hb, const int* blk_row, const int* blk_col, int nb, int nfree, double* Minv, int* bad);
 void pcg_launch_init(hipStream_t, const double* b, const double* Minv, int nfree, double* w, double* part, double* sc, const PcgCoarse& C);
@@ -84,7 +84,7 @@ void ba_launch_backsub(hipStream_t, const BaDev&);
 void ba_launch_index_check(hipStream_t, const int* edge_pose, const int* edge_point, int E, int P, int L, int* flags, int* pt_first);
 void ba_launch_index_pose_keys(hipStream_t, const int* edge_pose, const int* free_of, int E, int P, int nfree, unsigned* key, unsigned* val);
 void ba_launch_index_pose_first(hipStream_t, const unsigned* skey, int E, int nfree, int* pose_first);
-void ba_launch_update(hipStream_t, const BaDev&);
+void ba_launch_update(hipStream_t, const BaDev&, double* save_poses, double* save_points);
 int ba_scale_blocks(const BaDev&);
 void ba_launch_scale(hipStream_t, const BaDev&, double lambda, int add_pose_lambda, double* partial, double* out);
 void ba_launch_diag(hipStream_t, const BaDev&, double* tmp_ll, double* pp_diag, double* out_ll_max);
@@ -673,8 +673,8 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         return CCM_OK;
     };
     // chi2 (+ optionally scale) of the current state, summed over ranks
-    auto eval_chi2 = [&](double hd, bool with_scale, double lambda, double* chi, double* scale) -> int {
-        ba_launch_pose_rt(st, D);
+    auto eval_chi2 = [&](double hd, bool with_scale, double lambda, double* chi, double* scale, bool rt_current = false) -> int {
+        if (!rt_current) ba_launch_pose_rt(st, D);                             // (k_ba_update leaves the matrices of the poses it moved)
         if (E > 0) ba_launch_errors(st, D, hd, partial, scal);
         else CCM_HIP(c, hipMemsetAsync(scal, 0, 8, st));
         if (with_scale) ba_launch_scale(st, D, lambda, rank == 0 ? 1 : 0, partial, scal + 1);
@@ -707,6 +707,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     };
     double huber = opt->huber_delta > 0 ? opt->huber_delta : 0.0;
     bool first_eval = true;
+    CCM_HIP(c, hipMemcpyAsync(S.save_poses.p, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));     // the fixed keyframes' entries of the saved state
     tick(-1);
     for (int stage = 0; stage < 2 && !res->stopped; stage++) {
         const int iterations = stage == 0 ? opt->iterations : opt->iterations2;
@@ -720,12 +721,21 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         double lambda = 0, ni = 2;
         int nBad = 0;
         if ((rc = sync_stop())) return rc;
+        // computeActiveErrors + activeRobustChi2 at the top of an iteration (optimization_algorithm_levenberg.cpp:75-80) evaluate the state the
+        // last ACCEPTED trial left, which that trial has just evaluated -- same kernels, same state, same sums: the value, the errors
+        // and the pose matrices are carried over instead of computed again (one host round trip and three launches per iteration; a
+        // local BA is bound by exactly those).  After a rejected last trial (state restored) and with several ranks (the stop flag
+        // rides on this evaluation's all-reduce) the evaluation runs as before.
+        bool chi_carried = false;
+        double carried_chi = 0;
         for (int it = 0; it < iterations; it++) {
             if (stop_requested()) { res->stopped = 1; break; }                    // !terminate(), sparse_optimizer.cpp:376
             auto t0 = clk::now();
             RoctxRange lin_("ba:linearize");
             double currentChi = 0;
-            if ((rc = eval_chi2(huber, false, 0, &currentChi, nullptr))) return rc;
+            if (chi_carried && ranks == 1) currentChi = carried_chi;
+            else if ((rc = eval_chi2(huber, false, 0, &currentChi, nullptr))) return rc;
+            chi_carried = false;
             const double iniChi = currentChi;
             if (first_eval) { res->chi2_initial = currentChi; first_eval = false; }
             // buildSystem.  From the second iteration on lambda is known here, and the landmarks' share of the first trial's Schur step
@@ -754,9 +764,9 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
             do {
                 auto t1 = clk::now();
                 RoctxRange trial_("ba:trial (schur + solve + update)");
-                CCM_HIP(c, hipMemcpyAsync(S.save_poses.p, D.poses, 7 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));   // push
-                if (L) CCM_HIP(c, hipMemcpyAsync(S.save_points.p, D.points, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
+                // (push: k_ba_update saves the state it is about to change; the fixed keyframes' poses were copied once, above)
                 int ok2 = 1;
+                bool updated = false;
                 // The dense solve's verdict ("not positive definite") of a small, single-rank problem is read together with the
                 // trial's chi2 instead of in a round trip of its own (a local BA is launch- and round-trip-bound: three host syncs
                 // per trial were a fifth of the call): the trial's update is applied as if the solve had succeeded and, if it had
@@ -772,7 +782,10 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                                              S.blk_row.as<int>(), S.blk_col.as<int>(), nb, Hb); }
                     { ProfScope ps(c, CCM_PROF_BA_BSCHUR); sp_launch_bschur(st, D, D.bs); }
                     if ((rc = comm_allreduce_f64(c, Hb, 36 * (size_t)nb + (size_t)n, false))) return rc;
-                    sp_launch_add_lambda(st, S.diag_id.as<int>(), nfree, lambda, Hb);
+                    // (a system small enough for k_dense_small_solve gets its damping there)
+                    static const bool no_small = getenv("CCM_BA_NO_SMALL_SOLVE") && atoi(getenv("CCM_BA_NO_SMALL_SOLVE")) != 0;   // test switch
+                    const bool small_solve = !use_pcg && !no_small && n <= dense_small_max();
+                    if (!small_solve) sp_launch_add_lambda(st, S.diag_id.as<int>(), nfree, lambda, Hb);
                     tick(1);
                     t2 = clk::now();
                     if (!fine_timers) res->t_schur += secs(t1, t2);
@@ -892,13 +905,12 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                     }
                     if (!solved) {
                         // dense solve by the in-house block Gauss-Jordan (see dense_launch_solve for why not rocSOLVER)
-                        static const bool no_small = getenv("CCM_BA_NO_SMALL_SOLVE") && atoi(getenv("CCM_BA_NO_SMALL_SOLVE")) != 0;   // test switch
-                        CCM_HIP(c, hipMemsetAsync(info_dev, 0, 4, st));
-                        if (!no_small && n <= dense_small_max()) {
+                        if (small_solve) {
                             // a local BA's system: factored and solved by one workgroup in LDS, one launch (see k_dense_small_solve)
-                            if (dense_launch_small_solve(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, (int)n, D.bs, D.x, info_dev))
+                            if (dense_launch_small_solve(st, Hb, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, (int)n, D.bs, D.x, info_dev, lambda))
                                 return ccm_fail(c, CCM_E_DEVICE, "k_dense_small_solve: LDS request refused");
                         } else {
+                        CCM_HIP(c, hipMemsetAsync(info_dev, 0, 4, st));
                         const size_t npd = (size_t)dense_pitch(n);
                         CCM_RESERVE(c, S.Hs, (npd * npd + 48 * 48 + 8) * 8);
                         double* Hs = S.Hs.as<double>();
@@ -940,8 +952,9 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                 double tempChi = DBL_MAX, scale = 0;
                 if (ok2) {
                     if (L > 0) { ProfScope ps(c, CCM_PROF_BA_BACKSUB); ba_launch_backsub(st, D); }
-                    ba_launch_update(st, D);
-                    if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale))) return rc;     // synchronises the stream
+                    ba_launch_update(st, D, S.save_poses.as<double>(), S.save_points.as<double>());
+                    updated = true;
+                    if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale, true))) return rc;     // synchronises the stream
                     if (dense_info_pending && *dense_info != 0) { ok2 = 0; tempChi = DBL_MAX; scale = 0; }
                 }
                 scale += 1e-3;
@@ -953,13 +966,16 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                     ni = 2; currentChi = tempChi;                                   // discardTop
                 } else {
                     lambda *= ni; ni *= 2;
-                    CCM_HIP(c, hipMemcpyAsync(D.poses, S.save_poses.p, 7 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));   // pop
-                    if (L) CCM_HIP(c, hipMemcpyAsync(D.points, S.save_points.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
+                    if (updated) {                                                  // pop (a trial whose solve failed has not moved anything)
+                        CCM_HIP(c, hipMemcpyAsync(D.poses, S.save_poses.p, 7 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+                        if (L) CCM_HIP(c, hipMemcpyAsync(D.points, S.save_points.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
+                    }
                 }
                 qmax++;
                 tick(3);
                 if (!fine_timers) res->t_update += secs(t3, clk::now());
             } while (rho < 0 && qmax < 10 && !stop_requested());
+            if (rho > 0 && std::isfinite(currentChi)) { chi_carried = true; carried_chi = currentChi; }      // the last trial was accepted: currentChi is its chi2
             res->iterations_done++;
             res->chi2_final = currentChi; res->lambda_final = lambda;
             if (qmax == 10 || rho == 0) break;                                       // Terminate

@@ -274,16 +274,31 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev D)
     xl[2] = Di[6] * c0 + Di[7] * c1 + Di[8] * c2;
 }
 
-__global__ __launch_bounds__(256) void k_ba_update(BaDev D)
+// The state before the step goes to save_poses / save_points (the LM loop's push: a rejected step copies it back), and the
+// new poses' rotation matrices are written where k_ba_pose_rt would write them (same arithmetic) -- a local BA is bound by its
+// launches, and these were three of the sixteen of a trial.
+__global__ __launch_bounds__(256) void k_ba_update(BaDev D, double* __restrict__ save_poses, double* __restrict__ save_points)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < D.nfree) {
         const int p = D.pose_of_free[i];
-        double o[7];
-        ba_se3_exp_mul(D.x + 6 * i, D.poses + 7 * (long long)p, o);
+        double o[7], old[7];
+        for (int k = 0; k < 7; k++) old[k] = D.poses[7 * (long long)p + k];
+        for (int k = 0; k < 7; k++) save_poses[7 * (long long)p + k] = old[k];
+        ba_se3_exp_mul(D.x + 6 * i, old, o);
         for (int k = 0; k < 7; k++) D.poses[7 * (long long)p + k] = o[k];
+        double R[9];
+        ba_quat_to_R(o, R);
+        double* rt = D.Rt + 12 * (long long)p;
+        for (int k = 0; k < 9; k++) rt[k] = R[k];
+        rt[9] = o[4]; rt[10] = o[5]; rt[11] = o[6];
     }
-    if (i < D.L) for (int k = 0; k < 3; k++) D.points[3 * (long long)i + k] += D.x[6LL * D.nfree + 3 * (long long)i + k];
+    if (i < D.L)
+        for (int k = 0; k < 3; k++) {
+            const double v = D.points[3 * (long long)i + k];
+            save_points[3 * (long long)i + k] = v;
+            D.points[3 * (long long)i + k] = v + D.x[6LL * D.nfree + 3 * (long long)i + k];
+        }
 }
 
 // computeScale partial (optimization_algorithm_levenberg.cpp:182-189):
@@ -416,10 +431,10 @@ void ba_launch_backsub(hipStream_t s, const BaDev& D)
 {
     if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub<BA_LM_LANES>, dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D);
 }
-void ba_launch_update(hipStream_t s, const BaDev& D)
+void ba_launch_update(hipStream_t s, const BaDev& D, double* save_poses, double* save_points)
 {
     const int n = D.L > D.nfree ? D.L : D.nfree;
-    if (n > 0) hipLaunchKernelGGL(k_ba_update, dim3(nblk(n, 256)), dim3(256), 0, s, D);
+    if (n > 0) hipLaunchKernelGGL(k_ba_update, dim3(nblk(n, 256)), dim3(256), 0, s, D, save_poses, save_points);
 }
 int ba_scale_blocks(const BaDev& D) { return nblk(6LL * D.nfree + 3LL * D.L, 256); }
 void ba_launch_scale(hipStream_t s, const BaDev& D, double lambda, int add_pose_lambda, double* partial, double* out)

@@ -1575,8 +1575,10 @@ void ppcg_launch_publish(hipStream_t s, const double* part, int nfree, double* s
 // with the factorisation and the backward one reads the factor from the registers it already is in, so the factor is never written
 // anywhere.  (History at n = 120: matrix in LDS column by column 256 us, blocked in LDS 133 us, register tiles + the factor copied
 // to LDS for two separate substitution loops 116 us.)
+// The damping is added to the diagonal while the tiles are loaded and the verdict is WRITTEN (0 / 1) rather than or-ed in: the
+// launches of k_sp_add_lambda and of the memset of `bad` in front of this kernel were two of a local BA trial's thirteen.
 __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __restrict__ Hb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
-                                                              int nb, int n, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ bad)
+                                                              int nb, int n, const double* __restrict__ b, double* __restrict__ x, int* __restrict__ bad, double lambda)
 {
     extern __shared__ double ds_lds[];
     double* v = ds_lds;                      // [n] right-hand side -> y -> solution
@@ -1612,6 +1614,8 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
             for (int i = 0; i < 6; i++)
 #pragma unroll
                 for (int k = 0; k < i; k++) T[i][k] = T[k][i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) T[i][i] += lambda;
         }
     }
     double dinv[6] = { 0, 0, 0, 0, 0, 0 };                                   // a diagonal tile's owner: 1 / L_cc
@@ -1727,14 +1731,14 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
         __syncthreads();
     }
     for (int i = tid; i < n; i += DS_TPB) x[i] = v[i];
-    if (tid == 0 && s_bad) atomicOr(bad, 1);
+    if (tid == 0) *bad = s_bad ? 1 : 0;
 }
 int dense_small_max() { return DENSE_SMALL_MAX; }
-int dense_launch_small_solve(hipStream_t s, const double* Hb, const int* blk_row, const int* blk_col, int nb, int n, const double* b, double* x, int* bad)
+int dense_launch_small_solve(hipStream_t s, const double* Hb, const int* blk_row, const int* blk_col, int nb, int n, const double* b, double* x, int* bad, double lambda)
 {
     const size_t lds = (size_t)(n + 8) * sizeof(double);
     if (hipFuncSetAttribute((const void*)k_dense_small_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-    hipLaunchKernelGGL(k_dense_small_solve, dim3(1), dim3(DS_TPB), lds, s, Hb, blk_row, blk_col, nb, n, b, x, bad);
+    hipLaunchKernelGGL(k_dense_small_solve, dim3(1), dim3(DS_TPB), lds, s, Hb, blk_row, blk_col, nb, n, b, x, bad, lambda);
     return 0;
 }
 

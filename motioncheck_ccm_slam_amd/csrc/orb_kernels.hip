@@ -442,7 +442,6 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 // workgroup, 0.410 / 0.421 / 0.424 / 0.436 / 0.448 at 2 / 3 / 4 / 6 / 8, against 0.368.  A round of the loop (the extra barrier, the
 // band record and the kernel arguments re-read through scalar loads, 64 registers instead of 54) costs more than a fresh workgroup,
 // whose start-up the dispatcher overlaps with the seven others on the CU.  Not kept.
-// the survivor list holds `surv_cap` pixels; the detection rows are processed in blocks of surv_cap / pitch rows
 // NMS works on the list of scored pixels (FC_NZ entries) and the list of local maxima (FC_KEPT); a band that overflows
 // either list takes the per-cell row scan instead.
 #ifndef FC_NZ
@@ -455,9 +454,9 @@ __global__ __launch_bounds__(256) void k_cell_nms(const OrbGeom g, const OrbCell
 #ifndef FC_TPB
 #define FC_TPB 256              // threads per band workgroup (measured: 192 0.56, 256 0.52, 320 0.75, 384 0.82 ms)
 #endif
-// Survivors are appended per wave to the wave's own segment of the list (running count in a scalar register, no
-// atomic): a row block has at most surv_cap / 4 items of 4 pixels, a wave takes every (FC_TPB / 64)-th run of 64
-// items, so its segment never needs more than this many entries.
+// Survivors of the rejection test wait on the wave's own stack in LDS (running count in a scalar register, no atomic) and are scored
+// 64 at a time: the stack never holds more than 63 waiting entries + the 256 pixels of one run of 64 four-pixel items.
+// (surv_cap: rounds 1-2 pooled the survivors of a row block over the workgroup; the parameter is kept for the launcher's signature.)
 __host__ __device__ inline int fc_wave_cap(int surv_cap) { (void)surv_cap; return 320; }      // wave-local stack: at most 63 waiting + the 256 pixels of one item
 __host__ __device__ inline size_t fc_lds_bytes(int pitch, int bh, int surv_cap)
 {
@@ -1258,7 +1257,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_orient_desc: one wave per selected keypoint.
+// k_orient_desc: a wave per selected keypoint (small batches) or per OD_ITEMS keypoint slots (see the kernel).
 //   IC_Angle (ORBextractor.cpp:68-95) on the un-blurred level, cv::fastAtan2;
 //   GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101 (:1259; integer taps {18,34,49,55,49,34,18},
 //   SURVEY.md 12.6) evaluated only on the 37x37 neighbourhood the pattern can reach -- the sum

@@ -868,6 +868,25 @@ __device__ __forceinline__ int oct_nonempty(const int* cc, int p)
     return (cc[4 * p] > 0) + (cc[4 * p + 1] > 0) + (cc[4 * p + 2] > 0) + (cc[4 * p + 3] > 0);
 }
 
+// Diagnostic build only (-DOCT_STAMPS, tools/r03_oct_stamps.sh): the level-0 workgroup of frame 0 leaves the shader clock at its phase
+// boundaries; the shipped kernel contains none of this.
+#ifdef OCT_STAMPS
+__device__ unsigned long long oct_stamps[64];
+__device__ int oct_stamp_n;
+#define OCT_STAMP() do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { const int i__ = oct_stamp_n; if (i__ < 64) { oct_stamps[i__] = __builtin_amdgcn_s_memtime(); oct_stamp_n = i__ + 1; } } } while (0)
+extern "C" int ccm_debug_oct_stamps(unsigned long long* out, int* n)
+{
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(oct_stamp_n), 4, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const int zero = 0;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(oct_stamps), 64 * 8, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(oct_stamp_n), &zero, 4, 0, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+#else
+#define OCT_STAMP() do { } while (0)
+#endif
+#ifndef OCT_LDS_KEYS
+#define OCT_LDS_KEYS 2048       // candidates of a (frame, level) up to which the key-parallel form below is used (its keys and their node ids live in LDS)
+#endif
 #ifndef OCT_WAVES
 #define OCT_WAVES 4             // measured: 1 -> 0.22 ms, 2 -> 0.41, 4 -> 0.135, 8 -> 0.23 ms per 256 frames
 #endif
@@ -885,9 +904,10 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                                                const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
                                                unsigned* keysA, unsigned* keysB,
                                                unsigned* __restrict__ out, int* __restrict__ out_count,
-                                               int* __restrict__ status)
+                                               int* __restrict__ status, int key_parallel_on)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    OCT_STAMP();                                             // 0 start
     // blockIdx.y = level: the long-running fine levels are dispatched first
     const int level = blockIdx.y, f = blockIdx.x + g.frame0, lane = lane_id(), wv = threadIdx.x >> 6;
     const OrbLevel& L = g.lv[level];
@@ -903,6 +923,19 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
 
     unsigned* kb[2] = { keysA + (long long)f * g.keys_per_frame + L.key_first,
                         keysB + (long long)f * g.keys_per_frame + L.key_first };
+    // KEY-PARALLEL FORM (round 3; levels with at most OCT_LDS_KEYS candidates: every level of a 752 x 480 frame).  The reference moves
+    // a divided node's keys into its children's vectors, and until round 3 this kernel did the same: a stable 4-way partition of
+    // every divided node's key range, a wave per node -- half of the kernel's time, most lanes idle on nodes of ~10 keys
+    // (tools/r03_oct_stamps.sh).  But a key's position inside its node never matters: DivideNode keeps the keys in their original
+    // order, and the only thing read from a node's key list besides its length is "the best response, first key wins ties"
+    // (:912-928).  So the keys stay where the gather put them (LDS), every key carries the list position of its node, and a pass is
+    // a loop over KEYS: count the quadrants of the nodes that may be divided (LDS atomics: sums, order-free), and after the list
+    // bookkeeping (unchanged: it never looks at keys) move every key's node id to its child's or its survivor's new position.
+    // The final choice is an atomic max per node of (response, original order reversed).
+    unsigned* lkeys = reinterpret_cast<unsigned*>(shared_len + 4);                     // [OCT_LDS_KEYS]
+    unsigned short* node_of = reinterpret_cast<unsigned short*>(lkeys + OCT_LDS_KEYS);  // [OCT_LDS_KEYS] list position of the key's node
+    unsigned* best = reinterpret_cast<unsigned*>(node_of + OCT_LDS_KEYS);              // [cap]
+    unsigned short* surv_pos = reinterpret_cast<unsigned short*>(best + cap);          // [cap] new position of a node that is not divided
     const int N = L.quota;
     int* ocount = out_count + (long long)f * g.nlevels + level;
 
@@ -937,17 +970,49 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
             for (int u = 0; u < 4; u++) v[u] = sp[min(k + u, mycnt - 1)];
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if (k + u < mycnt && mydst + k + u < L.key_cap) kb[0][mydst + k + u] = v[u];
+                if (k + u < mycnt && mydst + k + u < L.key_cap) {
+                    kb[0][mydst + k + u] = v[u];
+                    if (mydst + k + u < OCT_LDS_KEYS) lkeys[mydst + k + u] = v[u];
+                }
         }
     }
     if (total > L.key_cap) { if (lane == 0) atomicOr(status, 1); total = L.key_cap; }
     const int n = total;
     if (n == 0 || N <= 0) { if (threadIdx.x == 0) *ocount = 0; return; }
+    const bool small = key_parallel_on && n <= OCT_LDS_KEYS;
     wave_sync_mem();
+    OCT_STAMP();                                             // 1 candidates gathered
 
     // ---- roots (:711-753): stable partition of all keys by (int)(x / hX) into kb[1]; wave w owns the w-th
     //      contiguous quarter of the 64-key chunks, its per-root counts go through cc[w][root]
     const int R = L.roots;
+    if (small) {
+        // roots, key-parallel: every key's root from its x, the roots' sizes by LDS atomics, empty roots dropped (list order = x order)
+        const int tid = threadIdx.x;
+        if (tid < ORB_MAX_ROOTS) cc[tid] = 0;
+        __syncthreads();
+        for (int k = tid; k < n; k += 64 * OCT_WAVES) {
+            int r = (int)((float)key_x(lkeys[k]) / L.hx); r = min(r, R - 1);
+            node_of[k] = (unsigned short)r;
+            atomicAdd(&cc[r], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int p = 0;
+            for (int r = 0; r < R; r++) {
+                gain[r] = p;                                   // root r's list position (unused for an empty root: no key points at it)
+                if (cc[r] == 0) continue;
+                cur.x0[p] = (short)(int)(L.hx * (float)r);
+                cur.x1[p] = (short)(int)(L.hx * (float)(r + 1));
+                cur.y0[p] = 0; cur.y1[p] = (short)L.bh;
+                cur.first[p] = 0; cur.count[p] = cc[r]; cur.buf[p] = 0;
+                p++;
+            }
+            *shared_len = p;
+        }
+        __syncthreads();
+        for (int k = tid; k < n; k += 64 * OCT_WAVES) node_of[k] = (unsigned short)gain[node_of[k]];
+    } else {
     const int nch = (n + 63) >> 6, cpw = (nch + OCT_WAVES - 1) / OCT_WAVES;
     const int ch0 = wv * cpw, ch1 = min(nch, ch0 + cpw);
     {
@@ -1025,10 +1090,12 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
             *shared_len = p;
         }
     }
+    }
     wave_sync_mem();
     int len = *shared_len;
 
     // ---- refinement passes
+    OCT_STAMP();                                             // 2 roots made
     bool finish = false, careful = false;
     int guard = 0;
     const unsigned long long lt = lanemask_lt();
@@ -1048,17 +1115,20 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         // (2) child key counts AND the stable 4-way partition of every such node's keys into the other scratch
-        //     buffer (DivideNode pushes keys in order, :681-695), four nodes per wave and step.  In careful mode
-        //     some of these nodes are not divided in this pass: their partitioned copy is then simply not used
-        //     (a node's key range belongs to it alone in both buffers, and its `buf` still names the intact one).
-        for (int k0 = wv; k0 < nc; k0 += 4 * OCT_WAVES) {
+        //     buffer (DivideNode pushes keys in order, :681-695), four nodes per wave and step.
+        //     In careful mode only the nodes up to the one that brings the list to N are divided (typically a third of the candidates:
+        //     35 of 110 on level 0 of the bench frames), and which ones is known only from ALL candidates' child counts: the counts are
+        //     taken first (no stores), the order is chosen, and only the chosen nodes are partitioned (round 3; before, every candidate
+        //     was partitioned and most copies thrown away: 51,000 of the kernel's 185,000 cycles, tools/r03_oct_stamps.sh).
+        auto divide = [&](int n_nodes, bool do_count, bool do_part) {
+        for (int k0 = wv; k0 < n_nodes; k0 += 4 * OCT_WAVES) {
             int pp[4], cn[4], sx[4], sy[4], fo[4], pb[4];
             unsigned k1[4], k2[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int kk = k0 + OCT_WAVES * u;
                 pp[u] = 0; cn[u] = 0; sx[u] = 0; sy[u] = 0; fo[u] = 0; pb[u] = 0;
-                if (kk < nc) {
+                if (kk < n_nodes) {
                     const int p = ord[kk];
                     pp[u] = p; cn[u] = cur.count[p];
                     sx[u] = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;       // x0 + ceil(w/2)  (:652)
@@ -1084,21 +1154,27 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                 const int q2 = lane + 64 < cnt ? (key_x(k2[u]) < csx ? 0 : 1) + (key_y(k2[u]) < csy ? 0 : 2) : -1;
                 const unsigned long long a0 = __ballot(q1 == 0), a1 = __ballot(q1 == 1), a2 = __ballot(q1 == 2), a3 = __ballot(q1 == 3);
                 const unsigned long long b0 = __ballot(q2 == 0), b1 = __ballot(q2 == 1), b2 = __ballot(q2 == 2), b3 = __ballot(q2 == 3);
-                int c0 = __popcll(a0) + __popcll(b0), c1 = __popcll(a1) + __popcll(b1);
-                int c2 = __popcll(a2) + __popcll(b2), c3 = __popcll(a3) + __popcll(b3);
-                for (int base = 128; base < cnt; base += 256) {            // a large node (the first passes): count the rest
-                    unsigned key[4];
+                int c0, c1, c2, c3;
+                if (do_count) {
+                    c0 = __popcll(a0) + __popcll(b0); c1 = __popcll(a1) + __popcll(b1);
+                    c2 = __popcll(a2) + __popcll(b2); c3 = __popcll(a3) + __popcll(b3);
+                    for (int base = 128; base < cnt; base += 256) {            // a large node (the first passes): count the rest
+                        unsigned key[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { const int i = base + 64 * j + lane; key[j] = i < cnt ? src[i] : 0u; }
+                        for (int j = 0; j < 4; j++) { const int i = base + 64 * j + lane; key[j] = i < cnt ? src[i] : 0u; }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int i = base + 64 * j + lane;
-                        const int q = i < cnt ? (key_x(key[j]) < csx ? 0 : 1) + (key_y(key[j]) < csy ? 0 : 2) : -1;
-                        c0 += __popcll(__ballot(q == 0)); c1 += __popcll(__ballot(q == 1));
-                        c2 += __popcll(__ballot(q == 2)); c3 += __popcll(__ballot(q == 3));
+                        for (int j = 0; j < 4; j++) {
+                            const int i = base + 64 * j + lane;
+                            const int q = i < cnt ? (key_x(key[j]) < csx ? 0 : 1) + (key_y(key[j]) < csy ? 0 : 2) : -1;
+                            c0 += __popcll(__ballot(q == 0)); c1 += __popcll(__ballot(q == 1));
+                            c2 += __popcll(__ballot(q == 2)); c3 += __popcll(__ballot(q == 3));
+                        }
                     }
+                    if (lane == 0) { cc[4 * pp[u]] = c0; cc[4 * pp[u] + 1] = c1; cc[4 * pp[u] + 2] = c2; cc[4 * pp[u] + 3] = c3; }
+                } else {                                                   // counted in an earlier call (careful mode)
+                    c0 = cc[4 * pp[u]]; c1 = cc[4 * pp[u] + 1]; c2 = cc[4 * pp[u] + 2]; c3 = cc[4 * pp[u] + 3];
                 }
-                if (lane == 0) { cc[4 * pp[u]] = c0; cc[4 * pp[u] + 1] = c1; cc[4 * pp[u] + 2] = c2; cc[4 * pp[u] + 3] = c3; }
+                if (!do_part) continue;
                 int r0 = 0, r1 = c0, r2 = c0 + c1, r3 = c0 + c1 + c2;
                 if (q1 == 0) dst[r0 + __popcll(a0 & lt)] = k1[u];
                 else if (q1 == 1) dst[r1 + __popcll(a1 & lt)] = k1[u];
@@ -1129,7 +1205,21 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                 }
             }
         }
+        };
+        if (small) {
+            for (int i = threadIdx.x; i < 4 * len; i += 64 * OCT_WAVES) cc[i] = 0;
+            __syncthreads();
+            for (int k = threadIdx.x; k < n; k += 64 * OCT_WAVES) {
+                const int p = node_of[k];
+                if (cur.count[p] > 1) {
+                    const unsigned key = lkeys[k];
+                    const int csx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2, csy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
+                    atomicAdd(&cc[4 * p + (key_x(key) < csx ? 0 : 1) + (key_y(key) < csy ? 0 : 2)], 1);
+                }
+            }
+        } else divide(nc, true, !careful);
         wave_sync_mem();
+        OCT_STAMP();                                         // pass: partition done
         // (3) the divided nodes in processing order: ord[k] = list position of the k-th
         int nd = nc;
         if (careful) {
@@ -1163,7 +1253,11 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                 run += __shfl(incl, 63, 64);
             }
             nd = m_c > 0 ? K + 1 : 0;
+            wave_sync_mem();                                 // (ord now lists the candidates in division order: every wave reads all of it)
+            if (!small) divide(nd, false, true);
+            wave_sync_mem();
         }
+        OCT_STAMP();                                         // pass: order chosen
         // (4) creation index of each divided node's first child; T = children created in this pass
         int T = 0;
         for (int base = 0; base < nd; base += 64) {
@@ -1190,6 +1284,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                 if (dest < cap) {
                     nxt.x0[dest] = cur.x0[p]; nxt.y0[dest] = cur.y0[p]; nxt.x1[dest] = cur.x1[p]; nxt.y1[dest] = cur.y1[p];
                     nxt.first[dest] = cur.first[p]; nxt.count[dest] = cur.count[p]; nxt.buf[dest] = cur.buf[p];
+                    surv_pos[p] = (unsigned short)dest;
                 }
             }
             nsurv += __popcll(m);
@@ -1227,8 +1322,31 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
             newExpand += wave_sum(gt1);
         }
         wave_sync_mem();
+        if (small) {
+            // every key follows its node: to the survivor's new position, or to the child of its quadrant (children are created in
+            // quadrant order, empty ones skipped, and pushed to the front one by one: creation index c -> position T - 1 - c)
+            for (int k = threadIdx.x; k < n; k += 64 * OCT_WAVES) {
+                const int p = node_of[k];
+                const int mk = mark[p];
+                int np;
+                if (mk == 0) np = surv_pos[p];
+                else {
+                    const unsigned key = lkeys[k];
+                    const int csx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2, csy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
+                    const int q = (key_x(key) < csx ? 0 : 1) + (key_y(key) < csy ? 0 : 2);
+                    int ci = cbase[mk - 1];
+                    if (q > 0) ci += cc[4 * p] > 0;
+                    if (q > 1) ci += cc[4 * p + 1] > 0;
+                    if (q > 2) ci += cc[4 * p + 2] > 0;
+                    np = T - 1 - ci;
+                }
+                node_of[k] = (unsigned short)np;
+            }
+            __syncthreads();
+        }
         { OctNodes t = cur; cur = nxt; nxt = t; }
         len = newlen;
+        OCT_STAMP();                                         // pass: new list built
         // (7) loop control (:837-905)
         if (len >= N || len == prev) finish = true;
         else if (!careful && len + 3 * newExpand > N) careful = true;
@@ -1236,6 +1354,17 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
 
     // ---- keep the best response of every node, first key wins ties (:912-928); order = list order
     unsigned* o = out + (long long)f * g.out_per_frame + L.out_first;
+    if (small) {
+        // best response per node, the first key among equals: max of response << 16 | (0xFFFF - original index)
+        for (int p = threadIdx.x; p < len; p += 64 * OCT_WAVES) best[p] = 0u;
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += 64 * OCT_WAVES) atomicMax(&best[node_of[k]], ((lkeys[k] >> 24) << 16) | (0xFFFFu - (unsigned)k));
+        __syncthreads();
+        for (int p = threadIdx.x; p < len && p < L.out_cap; p += 64 * OCT_WAVES) o[p] = lkeys[0xFFFFu - (best[p] & 0xFFFFu)];
+        if (threadIdx.x == 0) *ocount = min(len, L.out_cap);
+        OCT_STAMP();                                         // end
+        return;
+    }
     for (int base = 64 * wv; base < len; base += 64 * OCT_WAVES) {
         const int p = base + lane;
         if (p < len && p < L.out_cap) {
@@ -1254,6 +1383,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
         }
     }
     if (threadIdx.x == 0) *ocount = min(len, L.out_cap);
+    OCT_STAMP();                                             // end
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1524,7 +1654,7 @@ extern "C" hipError_t orb_upload_pattern()
     return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ccm_orb_pattern, 1024);
 }
 
-size_t orb_octree_lds_bytes(int list_cap) { return (size_t)list_cap * OCT_NODE_LDS + 64; }
+size_t orb_octree_lds_bytes(int list_cap) { return (size_t)list_cap * OCT_NODE_LDS + 64 + 6 * (size_t)OCT_LDS_KEYS + 8 * (size_t)list_cap; }
 
 void orb_launch_resize(hipStream_t s, const OrbGeom& g_dev, int level, int dw, int dh, int nframes)
 {
@@ -1561,8 +1691,9 @@ void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells
                        const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
                        unsigned* out, int* out_count, int* status)
 {
+    static const int key_parallel = !(getenv("CCM_OCT_KEY_PARALLEL") && atoi(getenv("CCM_OCT_KEY_PARALLEL")) == 0);      // 0: the partitioning form for every level (test switch)
     hipLaunchKernelGGL(k_octree, dim3(nframes, nlevels), dim3(64 * OCT_WAVES), orb_octree_lds_bytes(list_cap), s,
-                       g_dev, cells, slots, cell_count, keysA, keysB, out, out_count, status);
+                       g_dev, cells, slots, cell_count, keysA, keysB, out, out_count, status, key_parallel);
 }
 void orb_launch_orient_desc(hipStream_t s, const OrbGeom& g_dev, int out_per_frame, int nframes, const unsigned* sel,
                             const int* sel_count, ccm_keypoint* kps, uint8_t* desc, int* counts, int max_per_image,

@@ -904,7 +904,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                                                const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
                                                unsigned* keysA, unsigned* keysB,
                                                unsigned* __restrict__ out, int* __restrict__ out_count,
-                                               int* __restrict__ status, int key_parallel_on)
+                                               int* __restrict__ status, int reg_keys_on)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     OCT_STAMP();                                             // 0 start
@@ -933,8 +933,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
     // bookkeeping (unchanged: it never looks at keys) move every key's node id to its child's or its survivor's new position.
     // The final choice is an atomic max per node of (response, original order reversed).
     unsigned* lkeys = reinterpret_cast<unsigned*>(shared_len + 4);                     // [OCT_LDS_KEYS]
-    unsigned short* node_of = reinterpret_cast<unsigned short*>(lkeys + OCT_LDS_KEYS);  // [OCT_LDS_KEYS] list position of the key's node
-    unsigned* best = reinterpret_cast<unsigned*>(node_of + OCT_LDS_KEYS);              // [cap]
+    unsigned* best = lkeys + OCT_LDS_KEYS;                                               // [cap]
     unsigned short* surv_pos = reinterpret_cast<unsigned short*>(best + cap);          // [cap] new position of a node that is not divided
     const int N = L.quota;
     int* ocount = out_count + (long long)f * g.nlevels + level;
@@ -979,118 +978,62 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
     if (total > L.key_cap) { if (lane == 0) atomicOr(status, 1); total = L.key_cap; }
     const int n = total;
     if (n == 0 || N <= 0) { if (threadIdx.x == 0) *ocount = 0; return; }
-    const bool small = key_parallel_on && n <= OCT_LDS_KEYS;
+    const bool small = reg_keys_on && n <= OCT_LDS_KEYS;
     wave_sync_mem();
     OCT_STAMP();                                             // 1 candidates gathered
 
-    // ---- roots (:711-753): stable partition of all keys by (int)(x / hX) into kb[1]; wave w owns the w-th
-    //      contiguous quarter of the 64-key chunks, its per-root counts go through cc[w][root]
+    // ---- the loops over keys.  Up to OCT_LDS_KEYS candidates: the thread's keys (k = tid + 256 j) and their nodes' list positions
+    //      stay in REGISTERS through all passes (unrolled: the LDS reads of a thread's eight keys are independent and in flight
+    //      together).  More: the keys are read from kb[0] and the node ids live in kb[1] (thread t only ever touches the ids of its
+    //      own keys, so no barrier is needed for them).
+    const int tid = threadIdx.x;
     const int R = L.roots;
+    constexpr int OCT_KPT = OCT_LDS_KEYS / (64 * OCT_WAVES);
+    unsigned mykey[OCT_KPT]; int mynode[OCT_KPT];
+#pragma unroll
+    for (int j = 0; j < OCT_KPT; j++) { mykey[j] = 0u; mynode[j] = 0; }
     if (small) {
-        // roots, key-parallel: every key's root from its x, the roots' sizes by LDS atomics, empty roots dropped (list order = x order)
-        const int tid = threadIdx.x;
-        if (tid < ORB_MAX_ROOTS) cc[tid] = 0;
-        __syncthreads();
-        for (int k = tid; k < n; k += 64 * OCT_WAVES) {
-            int r = (int)((float)key_x(lkeys[k]) / L.hx); r = min(r, R - 1);
-            node_of[k] = (unsigned short)r;
-            atomicAdd(&cc[r], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int p = 0;
-            for (int r = 0; r < R; r++) {
-                gain[r] = p;                                   // root r's list position (unused for an empty root: no key points at it)
-                if (cc[r] == 0) continue;
-                cur.x0[p] = (short)(int)(L.hx * (float)r);
-                cur.x1[p] = (short)(int)(L.hx * (float)(r + 1));
-                cur.y0[p] = 0; cur.y1[p] = (short)L.bh;
-                cur.first[p] = 0; cur.count[p] = cc[r]; cur.buf[p] = 0;
-                p++;
-            }
-            *shared_len = p;
-        }
-        __syncthreads();
-        for (int k = tid; k < n; k += 64 * OCT_WAVES) node_of[k] = (unsigned short)gain[node_of[k]];
-    } else {
-    const int nch = (n + 63) >> 6, cpw = (nch + OCT_WAVES - 1) / OCT_WAVES;
-    const int ch0 = wv * cpw, ch1 = min(nch, ch0 + cpw);
-    {
-        int rc[ORB_MAX_ROOTS];
 #pragma unroll
-        for (int r = 0; r < ORB_MAX_ROOTS; r++) rc[r] = 0;
-        for (int ch = ch0; ch < ch1; ch += 4) {
-            unsigned key[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = (ch + u) * 64 + lane;
-                key[u] = (ch + u < ch1 && i < n) ? kb[0][i] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = (ch + u) * 64 + lane;
-                int r = -1;
-                if (ch + u < ch1 && i < n) { r = (int)((float)key_x(key[u]) / L.hx); r = min(r, R - 1); }
-#pragma unroll
-                for (int q = 0; q < ORB_MAX_ROOTS; q++) rc[q] += __popcll(__ballot(r == q));
-            }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < ORB_MAX_ROOTS; q++) cc[wv * ORB_MAX_ROOTS + q] = rc[q];
-        }
+        for (int j = 0; j < OCT_KPT; j++) { const int k = tid + 64 * OCT_WAVES * j; if (k < n) mykey[j] = lkeys[k]; }
     }
-    wave_sync_mem();
-    {
-        int rcount[ORB_MAX_ROOTS], rbase[ORB_MAX_ROOTS], run[ORB_MAX_ROOTS];
-        int acc = 0;
+    // fn(key, node, k); mode 0: node read, 1: node read and written, 2: node written
+    auto for_keys = [&](auto&& fn, int mode) {
+        if (small) {
 #pragma unroll
-        for (int q = 0; q < ORB_MAX_ROOTS; q++) {
-            int tot = 0, before = 0;
-#pragma unroll
-            for (int w = 0; w < OCT_WAVES; w++) {
-                const int c = cc[w * ORB_MAX_ROOTS + q];
-                before += w < wv ? c : 0;
-                tot += c;
-            }
-            rcount[q] = tot; rbase[q] = acc; run[q] = acc + before; acc += tot;
-        }
-        const unsigned long long lt = lanemask_lt();
-        for (int ch = ch0; ch < ch1; ch += 4) {
-            unsigned key[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = (ch + u) * 64 + lane;
-                key[u] = (ch + u < ch1 && i < n) ? kb[0][i] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = (ch + u) * 64 + lane;
-                int r = -1;
-                if (ch + u < ch1 && i < n) { r = (int)((float)key_x(key[u]) / L.hx); r = min(r, R - 1); }
-#pragma unroll
-                for (int q = 0; q < ORB_MAX_ROOTS; q++) {
-                    const unsigned long long m = __ballot(r == q);
-                    if (r == q) kb[1][run[q] + __popcll(m & lt)] = key[u];
-                    run[q] += __popcll(m);
-                }
+            for (int j = 0; j < OCT_KPT; j++) { const int k = tid + 64 * OCT_WAVES * j; if (k < n) fn(mykey[j], mynode[j], k); }
+        } else {
+            for (int k = tid; k < n; k += 64 * OCT_WAVES) {
+                const unsigned key = kb[0][k];
+                int node = mode == 2 ? 0 : (int)kb[1][k];
+                fn(key, node, k);
+                if (mode != 0) kb[1][k] = (unsigned)node;
             }
         }
-        if (threadIdx.x == 0) {                            // (the barrier below also orders these reads of cc before the passes reuse it)
-            int p = 0;
-#pragma unroll
-            for (int r = 0; r < ORB_MAX_ROOTS; r++) {
-                if (r >= R || rcount[r] == 0) continue;
-                cur.x0[p] = (short)(int)(L.hx * (float)r);
-                cur.x1[p] = (short)(int)(L.hx * (float)(r + 1));
-                cur.y0[p] = 0; cur.y1[p] = (short)L.bh;
-                cur.first[p] = rbase[r]; cur.count[p] = rcount[r]; cur.buf[p] = 1;
-                p++;
-            }
-            *shared_len = p;
+    };
+    // ---- roots (:711-753): every key's root from its x, the roots' sizes by LDS atomics, empty roots dropped (list order = x order)
+    if (tid < ORB_MAX_ROOTS) cc[tid] = 0;
+    __syncthreads();
+    for_keys([&](unsigned key, int& node, int) {
+        int r = (int)((float)key_x(key) / L.hx); r = min(r, R - 1);
+        node = r;
+        atomicAdd(&cc[r], 1);
+    }, 2);
+    __syncthreads();
+    if (tid == 0) {
+        int p = 0;
+        for (int r = 0; r < R; r++) {
+            gain[r] = p;                                       // root r's list position (an empty root has no key that would ask)
+            if (cc[r] == 0) continue;
+            cur.x0[p] = (short)(int)(L.hx * (float)r);
+            cur.x1[p] = (short)(int)(L.hx * (float)(r + 1));
+            cur.y0[p] = 0; cur.y1[p] = (short)L.bh;
+            cur.count[p] = cc[r];
+            p++;
         }
+        *shared_len = p;
     }
-    }
+    __syncthreads();
+    for_keys([&](unsigned, int& node, int) { node = gain[node]; }, 1);
     wave_sync_mem();
     int len = *shared_len;
 
@@ -1112,114 +1055,18 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
             if (dv) ord[nc + __popcll(m & lt)] = p;
             nc += __popcll(m);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // (2) child key counts AND the stable 4-way partition of every such node's keys into the other scratch
-        //     buffer (DivideNode pushes keys in order, :681-695), four nodes per wave and step.
-        //     In careful mode only the nodes up to the one that brings the list to N are divided (typically a third of the candidates:
-        //     35 of 110 on level 0 of the bench frames), and which ones is known only from ALL candidates' child counts: the counts are
-        //     taken first (no stores), the order is chosen, and only the chosen nodes are partitioned (round 3; before, every candidate
-        //     was partitioned and most copies thrown away: 51,000 of the kernel's 185,000 cycles, tools/r03_oct_stamps.sh).
-        auto divide = [&](int n_nodes, bool do_count, bool do_part) {
-        for (int k0 = wv; k0 < n_nodes; k0 += 4 * OCT_WAVES) {
-            int pp[4], cn[4], sx[4], sy[4], fo[4], pb[4];
-            unsigned k1[4], k2[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int kk = k0 + OCT_WAVES * u;
-                pp[u] = 0; cn[u] = 0; sx[u] = 0; sy[u] = 0; fo[u] = 0; pb[u] = 0;
-                if (kk < n_nodes) {
-                    const int p = ord[kk];
-                    pp[u] = p; cn[u] = cur.count[p];
-                    sx[u] = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2;       // x0 + ceil(w/2)  (:652)
-                    sy[u] = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
-                    fo[u] = cur.first[p]; pb[u] = cur.buf[p];
-                }
+        // (2) how many keys of every such node fall into each of its quadrants (n1..n4 of DivideNode, :684-694)
+        for (int i = tid; i < 4 * len; i += 64 * OCT_WAVES) cc[i] = 0;
+        __syncthreads();
+        for_keys([&](unsigned key, int& node, int) {
+            const int p = node;
+            if (cur.count[p] > 1) {
+                const int csx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2, csy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;   // x0 + ceil(w/2)  (:652)
+                atomicAdd(&cc[4 * p + (key_x(key) < csx ? 0 : 1) + (key_y(key) < csy ? 0 : 2)], 1);
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const unsigned* src = (pb[u] ? kb[1] : kb[0]) + fo[u];
-                k1[u] = lane < cn[u] ? src[lane] : 0u;
-                k2[u] = lane + 64 < cn[u] ? src[lane + 64] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int cnt = cn[u];
-                if (cnt == 0) continue;
-                const unsigned* src = (pb[u] ? kb[1] : kb[0]) + fo[u];
-                unsigned* dst = (pb[u] ? kb[0] : kb[1]) + fo[u];
-                const int csx = sx[u], csy = sy[u];
-                // n1,n2,n3,n4 (:684-694)
-                const int q1 = lane < cnt ? (key_x(k1[u]) < csx ? 0 : 1) + (key_y(k1[u]) < csy ? 0 : 2) : -1;
-                const int q2 = lane + 64 < cnt ? (key_x(k2[u]) < csx ? 0 : 1) + (key_y(k2[u]) < csy ? 0 : 2) : -1;
-                const unsigned long long a0 = __ballot(q1 == 0), a1 = __ballot(q1 == 1), a2 = __ballot(q1 == 2), a3 = __ballot(q1 == 3);
-                const unsigned long long b0 = __ballot(q2 == 0), b1 = __ballot(q2 == 1), b2 = __ballot(q2 == 2), b3 = __ballot(q2 == 3);
-                int c0, c1, c2, c3;
-                if (do_count) {
-                    c0 = __popcll(a0) + __popcll(b0); c1 = __popcll(a1) + __popcll(b1);
-                    c2 = __popcll(a2) + __popcll(b2); c3 = __popcll(a3) + __popcll(b3);
-                    for (int base = 128; base < cnt; base += 256) {            // a large node (the first passes): count the rest
-                        unsigned key[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) { const int i = base + 64 * j + lane; key[j] = i < cnt ? src[i] : 0u; }
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int i = base + 64 * j + lane;
-                            const int q = i < cnt ? (key_x(key[j]) < csx ? 0 : 1) + (key_y(key[j]) < csy ? 0 : 2) : -1;
-                            c0 += __popcll(__ballot(q == 0)); c1 += __popcll(__ballot(q == 1));
-                            c2 += __popcll(__ballot(q == 2)); c3 += __popcll(__ballot(q == 3));
-                        }
-                    }
-                    if (lane == 0) { cc[4 * pp[u]] = c0; cc[4 * pp[u] + 1] = c1; cc[4 * pp[u] + 2] = c2; cc[4 * pp[u] + 3] = c3; }
-                } else {                                                   // counted in an earlier call (careful mode)
-                    c0 = cc[4 * pp[u]]; c1 = cc[4 * pp[u] + 1]; c2 = cc[4 * pp[u] + 2]; c3 = cc[4 * pp[u] + 3];
-                }
-                if (!do_part) continue;
-                int r0 = 0, r1 = c0, r2 = c0 + c1, r3 = c0 + c1 + c2;
-                if (q1 == 0) dst[r0 + __popcll(a0 & lt)] = k1[u];
-                else if (q1 == 1) dst[r1 + __popcll(a1 & lt)] = k1[u];
-                else if (q1 == 2) dst[r2 + __popcll(a2 & lt)] = k1[u];
-                else if (q1 == 3) dst[r3 + __popcll(a3 & lt)] = k1[u];
-                r0 += __popcll(a0); r1 += __popcll(a1); r2 += __popcll(a2); r3 += __popcll(a3);
-                if (q2 == 0) dst[r0 + __popcll(b0 & lt)] = k2[u];
-                else if (q2 == 1) dst[r1 + __popcll(b1 & lt)] = k2[u];
-                else if (q2 == 2) dst[r2 + __popcll(b2 & lt)] = k2[u];
-                else if (q2 == 3) dst[r3 + __popcll(b3 & lt)] = k2[u];
-                r0 += __popcll(b0); r1 += __popcll(b1); r2 += __popcll(b2); r3 += __popcll(b3);
-                for (int base = 128; base < cnt; base += 256) {
-                    unsigned key[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { const int i = base + 64 * j + lane; key[j] = i < cnt ? src[i] : 0u; }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int i = base + 64 * j + lane;
-                        const int q = i < cnt ? (key_x(key[j]) < csx ? 0 : 1) + (key_y(key[j]) < csy ? 0 : 2) : -1;
-                        const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1);
-                        const unsigned long long m2 = __ballot(q == 2), m3 = __ballot(q == 3);
-                        if (q == 0) dst[r0 + __popcll(m0 & lt)] = key[j];
-                        else if (q == 1) dst[r1 + __popcll(m1 & lt)] = key[j];
-                        else if (q == 2) dst[r2 + __popcll(m2 & lt)] = key[j];
-                        else if (q == 3) dst[r3 + __popcll(m3 & lt)] = key[j];
-                        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
-                    }
-                }
-            }
-        }
-        };
-        if (small) {
-            for (int i = threadIdx.x; i < 4 * len; i += 64 * OCT_WAVES) cc[i] = 0;
-            __syncthreads();
-            for (int k = threadIdx.x; k < n; k += 64 * OCT_WAVES) {
-                const int p = node_of[k];
-                if (cur.count[p] > 1) {
-                    const unsigned key = lkeys[k];
-                    const int csx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2, csy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
-                    atomicAdd(&cc[4 * p + (key_x(key) < csx ? 0 : 1) + (key_y(key) < csy ? 0 : 2)], 1);
-                }
-            }
-        } else divide(nc, true, !careful);
+        }, 0);
         wave_sync_mem();
-        OCT_STAMP();                                         // pass: partition done
+        OCT_STAMP();                                         // pass: quadrants counted
         // (3) the divided nodes in processing order: ord[k] = list position of the k-th
         int nd = nc;
         if (careful) {
@@ -1253,9 +1100,6 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                 run += __shfl(incl, 63, 64);
             }
             nd = m_c > 0 ? K + 1 : 0;
-            wave_sync_mem();                                 // (ord now lists the candidates in division order: every wave reads all of it)
-            if (!small) divide(nd, false, true);
-            wave_sync_mem();
         }
         OCT_STAMP();                                         // pass: order chosen
         // (4) creation index of each divided node's first child; T = children created in this pass
@@ -1283,7 +1127,7 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                 const int dest = T + nsurv + __popcll(m & lt);
                 if (dest < cap) {
                     nxt.x0[dest] = cur.x0[p]; nxt.y0[dest] = cur.y0[p]; nxt.x1[dest] = cur.x1[p]; nxt.y1[dest] = cur.y1[p];
-                    nxt.first[dest] = cur.first[p]; nxt.count[dest] = cur.count[p]; nxt.buf[dest] = cur.buf[p];
+                    nxt.count[dest] = cur.count[p];
                     surv_pos[p] = (unsigned short)dest;
                 }
             }
@@ -1301,8 +1145,6 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                 const int px0 = cur.x0[p], py0 = cur.y0[p], px1 = cur.x1[p], py1 = cur.y1[p];
                 const int sx = px0 + (px1 - px0 + 1) / 2, sy = py0 + (py1 - py0 + 1) / 2;
                 int ci = cbase[k];
-                int kf = cur.first[p];
-                const int pb = cur.buf[p] ^ 1;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int c = cc[4 * p + q];
@@ -1312,77 +1154,52 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
                         nxt.x1[dest] = (short)((q & 1) ? px1 : sx);
                         nxt.y0[dest] = (short)((q & 2) ? sy : py0);
                         nxt.y1[dest] = (short)((q & 2) ? py1 : sy);
-                        nxt.first[dest] = kf; nxt.count[dest] = c; nxt.buf[dest] = (uint8_t)pb;
+                        nxt.count[dest] = c;
                         ci++;
                         gt1 += (c > 1);
                     }
-                    kf += c;
                 }
             }
             newExpand += wave_sum(gt1);
         }
         wave_sync_mem();
-        if (small) {
-            // every key follows its node: to the survivor's new position, or to the child of its quadrant (children are created in
-            // quadrant order, empty ones skipped, and pushed to the front one by one: creation index c -> position T - 1 - c)
-            for (int k = threadIdx.x; k < n; k += 64 * OCT_WAVES) {
-                const int p = node_of[k];
-                const int mk = mark[p];
-                int np;
-                if (mk == 0) np = surv_pos[p];
-                else {
-                    const unsigned key = lkeys[k];
-                    const int csx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2, csy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
-                    const int q = (key_x(key) < csx ? 0 : 1) + (key_y(key) < csy ? 0 : 2);
-                    int ci = cbase[mk - 1];
-                    if (q > 0) ci += cc[4 * p] > 0;
-                    if (q > 1) ci += cc[4 * p + 1] > 0;
-                    if (q > 2) ci += cc[4 * p + 2] > 0;
-                    np = T - 1 - ci;
-                }
-                node_of[k] = (unsigned short)np;
+        // (7) every key follows its node: to the survivor's new position, or to the child of its quadrant (children are created in
+        //     quadrant order, empty ones skipped: creation index c -> position T - 1 - c)
+        for_keys([&](unsigned key, int& node, int) {
+            const int p = node;
+            const int mk = mark[p];
+            if (mk == 0) node = surv_pos[p];
+            else {
+                const int csx = cur.x0[p] + (cur.x1[p] - cur.x0[p] + 1) / 2, csy = cur.y0[p] + (cur.y1[p] - cur.y0[p] + 1) / 2;
+                const int q = (key_x(key) < csx ? 0 : 1) + (key_y(key) < csy ? 0 : 2);
+                int ci = cbase[mk - 1];
+                if (q > 0) ci += cc[4 * p] > 0;
+                if (q > 1) ci += cc[4 * p + 1] > 0;
+                if (q > 2) ci += cc[4 * p + 2] > 0;
+                node = T - 1 - ci;
             }
-            __syncthreads();
-        }
+        }, 1);
+        __syncthreads();                                     // (these reads of the old list against the next pass's writes into it)
         { OctNodes t = cur; cur = nxt; nxt = t; }
         len = newlen;
         OCT_STAMP();                                         // pass: new list built
-        // (7) loop control (:837-905)
+        // (8) loop control (:837-905)
         if (len >= N || len == prev) finish = true;
         else if (!careful && len + 3 * newExpand > N) careful = true;
     }
 
-    // ---- keep the best response of every node, first key wins ties (:912-928); order = list order
+    // ---- keep the best response of every node, first key wins ties (:912-928); order = list order:
+    //      max of response << 24 | (0xFFFFFF - original index)   (at most 2^24 candidates per level: 4.2 M at the largest image)
     unsigned* o = out + (long long)f * g.out_per_frame + L.out_first;
-    if (small) {
-        // best response per node, the first key among equals: max of response << 16 | (0xFFFF - original index)
-        for (int p = threadIdx.x; p < len; p += 64 * OCT_WAVES) best[p] = 0u;
-        __syncthreads();
-        for (int k = threadIdx.x; k < n; k += 64 * OCT_WAVES) atomicMax(&best[node_of[k]], ((lkeys[k] >> 24) << 16) | (0xFFFFu - (unsigned)k));
-        __syncthreads();
-        for (int p = threadIdx.x; p < len && p < L.out_cap; p += 64 * OCT_WAVES) o[p] = lkeys[0xFFFFu - (best[p] & 0xFFFFu)];
-        if (threadIdx.x == 0) *ocount = min(len, L.out_cap);
-        OCT_STAMP();                                         // end
-        return;
+    for (int p = tid; p < len; p += 64 * OCT_WAVES) best[p] = 0u;
+    __syncthreads();
+    for_keys([&](unsigned key, int& node, int k) { atomicMax(&best[node], (key & 0xFF000000u) | (0xFFFFFFu - (unsigned)k)); }, 0);
+    __syncthreads();
+    for (int p = tid; p < len && p < L.out_cap; p += 64 * OCT_WAVES) {
+        const unsigned kidx = 0xFFFFFFu - (best[p] & 0xFFFFFFu);
+        o[p] = small ? lkeys[kidx] : kb[0][kidx];
     }
-    for (int base = 64 * wv; base < len; base += 64 * OCT_WAVES) {
-        const int p = base + lane;
-        if (p < len && p < L.out_cap) {
-            const unsigned* src = kb[cur.buf[p]] + cur.first[p];
-            const int cnt = cur.count[p];
-            unsigned best = src[0];
-            for (int k = 1; k < cnt; k += 4) {
-                unsigned key[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) key[u] = src[min(k + u, cnt - 1)];     // a repeated last key never replaces (strict >)
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if ((key[u] >> 24) > (best >> 24)) best = key[u];
-            }
-            o[p] = best;
-        }
-    }
-    if (threadIdx.x == 0) *ocount = min(len, L.out_cap);
+    if (tid == 0) *ocount = min(len, L.out_cap);
     OCT_STAMP();                                             // end
 }
 
@@ -1654,7 +1471,7 @@ extern "C" hipError_t orb_upload_pattern()
     return hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ccm_orb_pattern, 1024);
 }
 
-size_t orb_octree_lds_bytes(int list_cap) { return (size_t)list_cap * OCT_NODE_LDS + 64 + 6 * (size_t)OCT_LDS_KEYS + 8 * (size_t)list_cap; }
+size_t orb_octree_lds_bytes(int list_cap) { return (size_t)list_cap * OCT_NODE_LDS + 64 + 4 * (size_t)OCT_LDS_KEYS + 8 * (size_t)list_cap; }
 
 void orb_launch_resize(hipStream_t s, const OrbGeom& g_dev, int level, int dw, int dh, int nframes)
 {
@@ -1691,7 +1508,7 @@ void orb_launch_octree(hipStream_t s, const OrbGeom& g_dev, const OrbCell* cells
                        const unsigned* slots, const int* cell_count, unsigned* keysA, unsigned* keysB,
                        unsigned* out, int* out_count, int* status)
 {
-    static const int key_parallel = !(getenv("CCM_OCT_KEY_PARALLEL") && atoi(getenv("CCM_OCT_KEY_PARALLEL")) == 0);      // 0: the partitioning form for every level (test switch)
+    static const int key_parallel = !(getenv("CCM_OCT_REG_KEYS") && atoi(getenv("CCM_OCT_REG_KEYS")) == 0);      // 0: keys and node ids in global memory on every level (test switch: the form levels with > OCT_LDS_KEYS candidates take)
     hipLaunchKernelGGL(k_octree, dim3(nframes, nlevels), dim3(64 * OCT_WAVES), orb_octree_lds_bytes(list_cap), s,
                        g_dev, cells, slots, cell_count, keysA, keysB, out, out_count, status, key_parallel);
 }

@@ -133,7 +133,7 @@ def test_full_batch_properties(ctx, oracle):
             ctx.host_unregister(a)
 
 
-@pytest.mark.parametrize("env", [{"CCM_ORB_FUSED": "0"}, {"CCM_FC_PACKED": "0"}, {"CCM_ORB_CHUNK": "2"}, {"CCM_BF_VARIANT": "0"}])
+@pytest.mark.parametrize("env", [{"CCM_ORB_FUSED": "0"}, {"CCM_FC_PACKED": "0"}, {"CCM_ORB_CHUNK": "2"}, {"CCM_BF_VARIANT": "0"}, {"CCM_OCT_REG_KEYS": "0"}])
 def test_alternative_kernel_paths(env):
     """The paths the defaults do not take -- two-kernel FAST through a score map (cells wider than one LDS tile), the
     scalar rejection test, tiny upload chunks, the vector-ALU matcher (more than 2048 train rows) -- selected by their

@@ -895,11 +895,10 @@ extern "C" int ccm_debug_oct_stamps(unsigned long long* out, int* n)
 //  their barriers and the list bookkeeping every wave repeats, not by where the keys live.  Not kept.)
 // (90 registers = 5 workgroups per CU for 2048 workgroups; forcing 6 / 8 with -DOCT_WPE (40 / 96 bytes of spills) measured no gain:
 //  step 1.064 / 1.071 / 1.083 ms at 5 / 6 / 8 -- the kernel is the chain inside a workgroup, not the second round of workgroups)
-#ifdef OCT_WPE
-#define OCT_OCC __attribute__((amdgpu_waves_per_eu(OCT_WPE, OCT_WPE)))
-#else
-#define OCT_OCC
+#ifndef OCT_WPE
+#define OCT_WPE 5                // 96 registers: five workgroups per CU
 #endif
+#define OCT_OCC __attribute__((amdgpu_waves_per_eu(OCT_WPE, OCT_WPE)))
 __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom g, const OrbCell* __restrict__ cells,
                                                const unsigned* __restrict__ slots, const int* __restrict__ cell_count,
                                                unsigned* keysA, unsigned* keysB,
@@ -962,19 +961,24 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
             if (u == wv) { mydst = total + incl - cnt[u]; mycnt = cnt[u]; }
             total += __shfl(incl, 63, 64);
         }
+        OCT_STAMP();                                         // (diagnostic: counts and slot offsets known)
         const unsigned* sp = fslots + sfirst;
-        for (int k = 0; k < mycnt; k += 4) {
-            unsigned v[4];
+        // (eight loads in flight per cell -- a cell of the bench frames holds up to ~20 candidates: with four per trip this loop was
+        //  five dependent global round trips, twice: 30,000 of the kernel's 115,000 cycles, tools/r03_oct_stamps.sh; sixteen cost the
+        //  registers that keep five workgroups on a CU)
+        for (int k = 0; k < mycnt; k += 8) {
+            unsigned v[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = sp[min(k + u, mycnt - 1)];
+            for (int u = 0; u < 8; u++) v[u] = sp[min(k + u, mycnt - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < 8; u++)
                 if (k + u < mycnt && mydst + k + u < L.key_cap) {
                     kb[0][mydst + k + u] = v[u];
                     if (mydst + k + u < OCT_LDS_KEYS) lkeys[mydst + k + u] = v[u];
                 }
         }
     }
+    OCT_STAMP();                                             // (diagnostic: this wave's keys stored)
     if (total > L.key_cap) { if (lane == 0) atomicOr(status, 1); total = L.key_cap; }
     const int n = total;
     if (n == 0 || N <= 0) { if (threadIdx.x == 0) *ocount = 0; return; }
@@ -1074,14 +1078,22 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
             // order, so "created later" == smaller position
             // (the quadratic rank loop is most of this kernel's instructions: each wave ranks a quarter of the list)
             const int m_c = nc;
+            // (eight LDS reads in flight: one per step was 145 cycles a step, 17,500 of the kernel's 115,000 cycles; the counts in
+            //  registers read back with v_readlane measured slower still)
             for (int base = 64 * wv; base < len; base += 64 * OCT_WAVES) {
                 const int p = base + lane;
                 const int myc = p < len ? cur.count[p] : 0;
                 if (myc > 1) {
                     int rank = 0;
-                    for (int q = 0; q < len; q++) {
-                        const int cq = cur.count[q];
-                        rank += (cq > 1 && (cq > myc || (cq == myc && q < p))) ? 1 : 0;
+                    for (int q0 = 0; q0 < len; q0 += 8) {
+                        int cq[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) cq[u] = cur.count[min(q0 + u, len - 1)];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int q = q0 + u;
+                            rank += (q < len && cq[u] > 1 && (cq[u] > myc || (cq[u] == myc && q < p))) ? 1 : 0;
+                        }
                     }
                     ord[rank] = p;
                     gain[rank] = oct_nonempty(cc, p) - 1;

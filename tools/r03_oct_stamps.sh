@@ -20,7 +20,9 @@ for rep in range(3):
     assert lib.ccm_debug_oct_stamps(buf.ctypes.data, n.ctypes.data) == 0
 k = int(n[0]); t = buf[:k].astype(np.int64)
 print("stamps:", k, " total %d ticks" % (t[-1] - t[0]))
-print("start -> candidates gathered %d; -> roots made %d" % (t[1] - t[0], t[2] - t[1]))
+# stamps 1, 2: counts known in gather rounds 0 and 1; 3: wave 0's keys stored; 4: gathered (barrier); 5: roots
+print("start -> round 0 counts %d -> round 1 counts %d -> wave 0 stored %d -> barrier %d; -> roots made %d" % (t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]))
+t = t[3:]; k -= 3
 i = 3; p = 0
 while i + 2 < k:
     print("pass %d: partition %d, order %d, new list %d" % (p, t[i] - t[i - 1], t[i + 1] - t[i], t[i + 2] - t[i + 1])); i += 3; p += 1

@@ -819,15 +819,15 @@ __global__ __launch_bounds__(FC_TPB) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_octree: DistributeOctTree (ORBextractor.cpp:707-931), one workgroup of 4 waves per (frame, level): the per-node
-// key loops (child counts, 4-way partition) are dealt to the waves, the list bookkeeping is computed by every wave
+// k_octree: DistributeOctTree (ORBextractor.cpp:707-931), one workgroup of 4 waves per (frame, level): the loops over
+// keys are dealt to the threads (see KEY-PARALLEL FORM in the kernel), the list bookkeeping is computed by every wave
 // identically (same LDS values written four times) so that all loop control stays uniform across the block.
 //
 // The reference keeps nodes in a std::list, inserting children with push_front and erasing the
 // parent.  Equivalent array form used here: after a pass in which the nodes P_0..P_{m-1} are divided
 // in processing order, the new list is   reverse(children in creation order) ++ (old list minus the
-// divided nodes).  Keys stay grouped by node inside a ping-pong scratch array; dividing a node is a
-// stable 4-way partition of its key range (DivideNode pushes keys in order, :681-695).
+// divided nodes).  The keys are not moved (rounds 1-2 kept them grouped by node in a ping-pong scratch array, a stable 4-way
+// partition per divided node: DivideNode pushes keys in order, :681-695): every key carries the list position of its node.
 // "Full" passes divide every node holding more than one key, in list order (:774-833).  Once
 // size + 3*nToExpand > N the reference switches to dividing in descending (size, address) order and
 // stops as soon as size >= N (:841-905); equal sizes are ordered by creation (later first), the
@@ -922,12 +922,12 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
 
     unsigned* kb[2] = { keysA + (long long)f * g.keys_per_frame + L.key_first,
                         keysB + (long long)f * g.keys_per_frame + L.key_first };
-    // KEY-PARALLEL FORM (round 3; levels with at most OCT_LDS_KEYS candidates: every level of a 752 x 480 frame).  The reference moves
+    // KEY-PARALLEL FORM (round 3).  The reference moves
     // a divided node's keys into its children's vectors, and until round 3 this kernel did the same: a stable 4-way partition of
     // every divided node's key range, a wave per node -- half of the kernel's time, most lanes idle on nodes of ~10 keys
     // (tools/r03_oct_stamps.sh).  But a key's position inside its node never matters: DivideNode keeps the keys in their original
     // order, and the only thing read from a node's key list besides its length is "the best response, first key wins ties"
-    // (:912-928).  So the keys stay where the gather put them (LDS), every key carries the list position of its node, and a pass is
+    // (:912-928).  So the keys stay where the gather put them, every key carries the list position of its node, and a pass is
     // a loop over KEYS: count the quadrants of the nodes that may be divided (LDS atomics: sums, order-free), and after the list
     // bookkeeping (unchanged: it never looks at keys) move every key's node id to its child's or its survivor's new position.
     // The final choice is an atomic max per node of (response, original order reversed).
@@ -937,10 +937,6 @@ __global__ __launch_bounds__(64 * OCT_WAVES) OCT_OCC void k_octree(const OrbGeom
     const int N = L.quota;
     int* ocount = out_count + (long long)f * g.nlevels + level;
 
-    // Every loop over keys below is a chain of dependent global-memory round trips, and the kernel's time is the
-    // length of those chains (the level-0 tree of one frame took 100 us with one chunk per trip), so: the chunks
-    // of a loop are dealt to the four waves, and each wave issues the loads of four chunks (or of four small
-    // nodes) before it touches the first.
     // ---- gather this level's candidates in cell-major order into kb[0]: 64 cells per wave and round
     const int* ccount = cell_count + (long long)f * g.ncells + L.cell_first;
     const unsigned* fslots = slots + (long long)f * g.slots_per_frame;

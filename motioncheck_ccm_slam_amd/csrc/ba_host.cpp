@@ -28,7 +28,7 @@ int comm_allreduce_f64(ccm_ctx* c, double* dev, size_t n, bool max_op);
 void ba_launch_pose_rt(hipStream_t, const BaDev&);
 int ba_errors_blocks(const BaDev&);
 void ba_launch_errors(hipStream_t, const BaDev&, double hd, double* partial, double* out);
-void ba_launch_linearize(hipStream_t, const BaDev&, double hd, double lambda);
+void ba_launch_linearize(hipStream_t, const BaDev&, double hd, double lambda, bool keep_hpl, bool landmarks_only);
 int comm_allreduce_u8_max(ccm_ctx* c, uint8_t* dev, size_t n);
 // ba_sparse.hip
 size_t sp_scan_temp_bytes(size_t n);
@@ -80,7 +80,7 @@ void pcg_launch_coarse_invert(hipStream_t, double* A, int ncp, double* D, int* b
 int pcg_coarse_pitch(int nfree);
 int dense_pitch(long long n);
 void dense_launch_solve(hipStream_t, double* A, int n, int lda, const double* b, double* x, int* bad);
-void ba_launch_backsub(hipStream_t, const BaDev&);
+void ba_launch_backsub(hipStream_t, const BaDev&, double lambda);
 void ba_launch_index_check(hipStream_t, const int* edge_pose, const int* edge_point, int E, int P, int L, int* flags, int* pt_first);
 void ba_launch_index_pose_keys(hipStream_t, const int* edge_pose, const int* free_of, int E, int P, int nfree, unsigned* key, unsigned* val);
 void ba_launch_index_pose_first(hipStream_t, const unsigned* skey, int E, int nfree, int* pose_first);
@@ -741,8 +741,11 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
             // buildSystem.  From the second iteration on lambda is known here, and the landmarks' share of the first trial's Schur step
             // (Dinv, db, Z, ce) is computed by the same kernel
             const bool fused_schur = it > 0 && nfree > 0 && lambda > 0;
-            { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_linearize(st, D, huber, fused_schur ? lambda : 0.0); }
+            // (and without Hpl, which only a repeated trial reads: see k_ba_lin_landmark MODE 2)
+            static const bool keep_hpl = getenv("CCM_BA_KEEP_HPL") && atoi(getenv("CCM_BA_KEEP_HPL")) != 0;          // test / A-B switch
+            { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_linearize(st, D, huber, fused_schur ? lambda : 0.0, keep_hpl, false); }
             bool landmark_share_ready = fused_schur;
+            bool hpl_valid = !fused_schur || keep_hpl;
             if (it == 0) {                                                          // computeLambdaInit
                 ba_launch_diag(st, D, S.tmp_ll.as<double>(), S.pp_diag.as<double>(), scal + 5);
                 if (L == 0) CCM_HIP(c, hipMemsetAsync(scal + 5, 0, 8, st));
@@ -775,7 +778,17 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                 bool dense_info_pending = false;
                 auto t2 = t1;
                 if (nfree > 0) {
-                    if (!landmark_share_ready) { ProfScope ps(c, CCM_PROF_BA_DINV_Y); sp_launch_dinv(st, D, lambda); }
+                    if (!landmark_share_ready) {
+                        ProfScope ps(c, CCM_PROF_BA_DINV_Y);
+                        if (!hpl_valid) {
+                            // a rejected trial of an iteration linearised without Hpl: the state is the linearisation point again (pop),
+                            // the pose matrices are the rejected trial's
+                            ba_launch_pose_rt(st, D);
+                            ba_launch_linearize(st, D, huber, 0.0, true, true);
+                            hpl_valid = true;
+                        }
+                        sp_launch_dinv(st, D, lambda);
+                    }
                     landmark_share_ready = false;                          // a repeated trial has another lambda
                     { ProfScope ps(c, CCM_PROF_BA_SCHUR_BLOCKS);
                       sp_launch_schur_blocks(st, D, S.Y.as<double>(), S.sp_val2.as<unsigned long long>(), S.seg_start.as<int>(), S.seg_end.as<int>(),
@@ -951,7 +964,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                 res->trials++;
                 double tempChi = DBL_MAX, scale = 0;
                 if (ok2) {
-                    if (L > 0) { ProfScope ps(c, CCM_PROF_BA_BACKSUB); ba_launch_backsub(st, D); }
+                    if (L > 0) { ProfScope ps(c, CCM_PROF_BA_BACKSUB); ba_launch_backsub(st, D, lambda); }
                     ba_launch_update(st, D, S.save_poses.as<double>(), S.save_points.as<double>());
                     updated = true;
                     if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale, true))) return rc;     // synchronises the stream
@@ -959,6 +972,10 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                 }
                 scale += 1e-3;
                 rho = ok2 ? (currentChi - tempChi) / scale : -1.0;
+                // test switch: the first trial of iteration N is treated as rejected (the repeated-trial path -- pop, another lambda,
+                // Hpl rebuilt -- on graphs whose trials are all accepted)
+                static const int reject_at = getenv("CCM_BA_TEST_REJECT_AT") ? atoi(getenv("CCM_BA_TEST_REJECT_AT")) : -1;
+                if (it == reject_at && qmax == 0) rho = -1.0;
                 if (rho > 0 && std::isfinite(tempChi)) {
                     double alpha = 1. - std::pow((2 * rho - 1), 3);
                     alpha = std::min(alpha, 2. / 3.);

@@ -90,37 +90,69 @@ __device__ __forceinline__ double ba_group_sum(double v)
     for (int d = 1; d < G; d <<= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
-// FUSE (LM iterations after the first, whose lambda is known before the linearisation): the landmark's share of the Schur step rides
-// along -- Dinv = (Hll + lambda I)^-1, db = Dinv b_l, and per edge Z = Hpl L^-T and ce = Hpl db, from the Hpl blocks the group has
-// just written -- instead of k_sp_dinv + k_sp_edge_y re-reading Hll and the 260 MB of Hpl (config 5) in launches of their own.
-template <int G, bool FUSE>
+// MODE 0: Hll, b_l and Hpl per edge (the first LM iteration, whose lambda comes out of this very linearisation).
+// MODE 1 (lambda known before the linearisation: every later iteration): the landmark's share of the Schur step rides along --
+// Dinv = (Hll + lambda I)^-1, db = Dinv b_l, and per edge Z = Hpl L^-T and ce = Hpl db, from the Hpl blocks the group has just
+// written -- instead of k_sp_dinv + k_sp_edge_y re-reading Hll and the 260 MB of Hpl (config 5) in launches of their own.
+// MODE 2: the same share WITHOUT Hpl.  After the first iteration nothing but this kernel's own tail read the array (the Schur product
+// and the back-substitution work from Z, the reduced right-hand side from ce), and its 144 bytes per edge were 36 % of the bytes the
+// kernel writes -- a kernel that runs at the rate its scattered 8-byte stores drain (2.2 TB/s, profiles/r03f_gba_counters.txt).  The
+// second pass evaluates the edge again instead (its operands are the first pass's, still in the L2) and forms Hpl in registers.  A
+// trial that is REJECTED needs Z for another lambda: the host then rebuilds Hpl with MODE 0 (rare: no iteration of config 5).
+// The G lanes of a landmark hold one block of NV 16-byte values each (one edge's Z, ce or Hpl) for the edges eb .. eb + G - 1, which lie
+// one after the other in the output array.  Stored lane by lane, one store instruction touches 64 different lines, 16 bytes each, and
+// the kernel runs at the rate those partial lines drain; passed through LDS the group writes the same bytes as runs of G x 16 = 128.
+// (Lanes of one wave: LDS operations of a wave complete in program order, no barrier.)
+template <int G, int NV>
+__device__ __forceinline__ void lm_store_group(double2* stage_group, int g, bool have, const double* v, double2* out_group, int n_edges)
+{
+    if (have) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) stage_group[g * NV + i] = make_double2(v[2 * i], v[2 * i + 1]);
+    }
+    const int nq = n_edges * NV;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int q = j * G + g;
+        if (q < nq) out_group[q] = stage_group[q];
+    }
+}
+template <int G, int MODE>
 __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_delta, double lambda)
 {
+    __shared__ double2 stage[256 * 9];
     const int gt = blockIdx.x * 256 + threadIdx.x;
     const int l = gt / G, g = gt - l * G;
     const bool live = l < D.L;
+    double2* stage_group = stage + 9 * (threadIdx.x - g);
     double H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, b[3] = { 0, 0, 0 };
     const double* pt = D.points + 3 * (long long)(live ? l : 0);
     const double p3[3] = { pt[0], pt[1], pt[2] };
     const int e0 = live ? D.pt_first[l] : 0, e1 = live ? D.pt_first[l + 1] : 0;
-    for (int e = e0 + g; e < e1; e += G) {
-        double* Hx = D.Hpl + 18 * (long long)e;
-        if (!D.active[e]) { for (int i = 0; i < 18; i++) Hx[i] = 0; continue; }
-        const int pi = D.edge_pose[e];
-        double er[2], A[6], B[12];
-        ba_edge_eval(D.Rt + 12 * (long long)pi, D.intr + 4 * (long long)pi, p3, D.obs + 2 * (long long)e, er, A, B, nullptr);
-        const double om = D.info[e];
-        double r0, r1 = 1.;
-        if (huber_delta > 0) ba_huber(om * (er[0] * er[0] + er[1] * er[1]), huber_delta, &r0, &r1);
-        const double w = r1 * om;
-        const double g0 = -om * er[0] * r1, g1 = -om * er[1] * r1;
-        for (int i = 0; i < 3; i++) {
-            b[i] += A[i] * g0 + A[3 + i] * g1;
-            for (int j = 0; j < 3; j++) H[i * 3 + j] += w * (A[i] * A[j] + A[3 + i] * A[3 + j]);
+    for (int eb = e0; eb < e1; eb += G) {                            // (the same trip count for the G lanes of a landmark)
+        const int e = eb + g;
+        const bool have = e < e1;
+        double Hx[18];
+        for (int i = 0; i < 18; i++) Hx[i] = 0;
+        if (have && D.active[e]) {
+            const int pi = D.edge_pose[e];
+            double er[2], A[6], B[12];
+            ba_edge_eval(D.Rt + 12 * (long long)pi, D.intr + 4 * (long long)pi, p3, D.obs + 2 * (long long)e, er, A, B, nullptr);
+            const double om = D.info[e];
+            double r0, r1 = 1.;
+            if (huber_delta > 0) ba_huber(om * (er[0] * er[0] + er[1] * er[1]), huber_delta, &r0, &r1);
+            const double w = r1 * om;
+            const double g0 = -om * er[0] * r1, g1 = -om * er[1] * r1;
+            for (int i = 0; i < 3; i++) {
+                b[i] += A[i] * g0 + A[3 + i] * g1;
+                for (int j = 0; j < 3; j++) H[i * 3 + j] += w * (A[i] * A[j] + A[3 + i] * A[3 + j]);
+            }
+            if (MODE != 2 && D.free_of[pi] >= 0) {
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 3; j++) Hx[i * 3 + j] = w * (B[i] * A[j] + B[6 + i] * A[3 + j]);
+            }
         }
-        const bool fr = D.free_of[pi] >= 0;
-        for (int i = 0; i < 6; i++)
-            for (int j = 0; j < 3; j++) Hx[i * 3 + j] = fr ? w * (B[i] * A[j] + B[6 + i] * A[3 + j]) : 0.0;
+        if (MODE != 2) lm_store_group<G, 9>(stage_group, g, have, Hx, reinterpret_cast<double2*>(D.Hpl + 18 * (long long)eb), min(G, e1 - eb));
     }
     if (G > 1) {
 #pragma unroll
@@ -132,7 +164,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_d
         for (int i = 0; i < 9; i++) D.Hll[9 * (long long)l + i] = H[i];
         for (int i = 0; i < 3; i++) D.bl[3 * (long long)l + i] = b[i];
     }
-    if (FUSE && live) {
+    if (MODE != 0 && live) {
         double Dm[9], Di[9], f[6], d[3];
         for (int i = 0; i < 9; i++) Dm[i] = H[i];
         Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
@@ -145,11 +177,34 @@ __global__ __launch_bounds__(256) void k_ba_lin_landmark(BaDev D, double huber_d
             for (int i = 0; i < 9; i++) D.Dinv[9 * (long long)l + i] = Di[i];
             for (int i = 0; i < 3; i++) D.db[3 * (long long)l + i] = d[i];
         }
-        for (int e = e0 + g; e < e1; e += G) {                       // this lane's edges again: their Hpl blocks are its own stores
-            const double* Hx = D.Hpl + 18 * (long long)e;
+        for (int eb = e0; eb < e1; eb += G) {                        // this lane's edges again
+            const int e = eb + g;
+            const bool have = e < e1;
             double Bx[18];
-            for (int i = 0; i < 18; i++) Bx[i] = Hx[i];
-            ba_edge_z_c(Bx, f, d, D.Z + 18 * (long long)e, D.ce + 6 * (long long)e);
+            for (int i = 0; i < 18; i++) Bx[i] = 0;
+            if (MODE == 1) {                                         // their Hpl blocks are the group's own stores
+                if (have) {
+                    const double2* Hx = reinterpret_cast<const double2*>(D.Hpl + 18 * (long long)e);
+                    for (int i = 0; i < 9; i++) { const double2 v = Hx[i]; Bx[2 * i] = v.x; Bx[2 * i + 1] = v.y; }
+                }
+            } else if (have) {
+                const int pi = D.edge_pose[e];
+                if (D.active[e] && D.free_of[pi] >= 0) {
+                    double er[2], A[6], B[12];
+                    ba_edge_eval(D.Rt + 12 * (long long)pi, D.intr + 4 * (long long)pi, p3, D.obs + 2 * (long long)e, er, A, B, nullptr);
+                    const double om = D.info[e];
+                    double r0, r1 = 1.;
+                    if (huber_delta > 0) ba_huber(om * (er[0] * er[0] + er[1] * er[1]), huber_delta, &r0, &r1);
+                    const double w = r1 * om;
+                    for (int i = 0; i < 6; i++)
+                        for (int j = 0; j < 3; j++) Bx[i * 3 + j] = w * (B[i] * A[j] + B[6 + i] * A[3 + j]);
+                }
+            }
+            double zz[18], cc[6];
+            ba_edge_z_c(Bx, f, d, zz, cc);
+            const int ne = min(G, e1 - eb);
+            lm_store_group<G, 9>(stage_group, g, have, zz, reinterpret_cast<double2*>(D.Z + 18 * (long long)eb), ne);
+            lm_store_group<G, 3>(stage_group, g, have, cc, reinterpret_cast<double2*>(D.ce + 6 * (long long)eb), ne);
         }
     }
 }
@@ -248,30 +303,38 @@ __global__ __launch_bounds__(256) void k_ba_lin_pose_wave(BaDev D, double huber_
     }
 }
 
+// x_l = Dinv (b_l - sum_e Hpl_e^T x_p(e)) with Hpl_e = Z_e L^T (L L^T = Hll + lambda I, Z the trial's Schur operand): Dinv b_l = db and
+// Dinv L = L^-T, so x_l = db - L^-T sum_e Z_e^T x_p(e) -- read from the array the Schur product has just used, which lets the
+// linearisation drop Hpl (k_ba_lin_landmark MODE 2).
 template <int G>
-__global__ __launch_bounds__(256) void k_ba_backsub(BaDev D)
+__global__ __launch_bounds__(256) void k_ba_backsub(BaDev D, double lambda)
 {
     const int gt = blockIdx.x * 256 + threadIdx.x;
     const int l = gt / G, g = gt - l * G;
     const bool live = l < D.L;
     const long long ll = live ? l : 0;
-    double c0 = 0, c1 = 0, c2 = 0;
-    if (g == 0) { c0 = D.bl[3 * ll]; c1 = D.bl[3 * ll + 1]; c2 = D.bl[3 * ll + 2]; }
+    double t0 = 0, t1 = 0, t2 = 0;
     const int e0 = live ? D.pt_first[l] : 0, e1 = live ? D.pt_first[l + 1] : 0;
     for (int e = e0 + g; e < e1; e += G) {
         const int f = D.free_of[D.edge_pose[e]];
         if (f < 0 || !D.active[e]) continue;
-        const double* Bi = D.Hpl + 18 * (long long)e;
+        const double2* Zv = reinterpret_cast<const double2*>(D.Z + 18 * (long long)e);
+        double Zi[18];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const double2 v = Zv[i]; Zi[2 * i] = v.x; Zi[2 * i + 1] = v.y; }
         const double* xp = D.x + 6 * f;
-        for (int i = 0; i < 6; i++) { c0 -= Bi[i * 3] * xp[i]; c1 -= Bi[i * 3 + 1] * xp[i]; c2 -= Bi[i * 3 + 2] * xp[i]; }
+        for (int i = 0; i < 6; i++) { t0 += Zi[i * 3] * xp[i]; t1 += Zi[i * 3 + 1] * xp[i]; t2 += Zi[i * 3 + 2] * xp[i]; }
     }
-    if (G > 1) { c0 = ba_group_sum<G>(c0); c1 = ba_group_sum<G>(c1); c2 = ba_group_sum<G>(c2); }
+    if (G > 1) { t0 = ba_group_sum<G>(t0); t1 = ba_group_sum<G>(t1); t2 = ba_group_sum<G>(t2); }
     if (!live || g != 0) return;
-    const double* Di = D.Dinv + 9 * (long long)l;
-    double* xl = D.x + 6LL * D.nfree + 3 * (long long)l;
-    xl[0] = Di[0] * c0 + Di[1] * c1 + Di[2] * c2;
-    xl[1] = Di[3] * c0 + Di[4] * c1 + Di[5] * c2;
-    xl[2] = Di[6] * c0 + Di[7] * c1 + Di[8] * c2;
+    double f[6];
+    ba_chol3(D.Hll + 9 * ll, lambda, f);
+    const double y2 = t2 * f[5];                                      // L^T y = t
+    const double y1 = (t1 - f[4] * y2) * f[3];
+    const double y0 = (t0 - f[1] * y1 - f[2] * y2) * f[0];
+    const double* db = D.db + 3 * ll;
+    double* xl = D.x + 6LL * D.nfree + 3 * ll;
+    xl[0] = db[0] - y0; xl[1] = db[1] - y1; xl[2] = db[2] - y2;
 }
 
 // The state before the step goes to save_poses / save_points (the LM loop's push: a rejected step copies it back), and the
@@ -360,11 +423,15 @@ void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial,
 #ifndef BA_LM_LANES
 #define BA_LM_LANES 8                     // lanes that share a landmark in k_ba_lin_landmark / k_ba_backsub (measured: see DESIGN.md)
 #endif
-// lambda > 0: the landmarks' share of the Schur step for that lambda is computed along (FUSE above)
-void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd, double lambda)
+// lambda > 0: the landmarks' share of the Schur step for that lambda is computed along (MODE 1, or MODE 2 when the caller can do
+// without Hpl); landmarks_only: the rebuild of Hpl after a rejected trial of a MODE 2 iteration
+void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd, double lambda, bool keep_hpl, bool landmarks_only)
 {
-    if (D.L > 0 && lambda > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, true>), dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D, hd, lambda);
-    else if (D.L > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, false>), dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D, hd, 0.0);     // a zero-size grid is a launch error
+    const dim3 grid(nblk((long long)BA_LM_LANES * D.L, 256));                                       // a zero-size grid is a launch error
+    if (D.L > 0 && lambda > 0 && keep_hpl) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, 1>), grid, dim3(256), 0, s, D, hd, lambda);
+    else if (D.L > 0 && lambda > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, 2>), grid, dim3(256), 0, s, D, hd, lambda);
+    else if (D.L > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, 0>), grid, dim3(256), 0, s, D, hd, 0.0);
+    if (landmarks_only) return;
     // few keyframes with long edge lists (local BA): a workgroup per keyframe; maps with thousands of keyframes: a wave each (measured:
     // the workgroup form costs config 5 another 60 us per linearisation, the wave form costs config 4 40 us)
     // (16 waves per keyframe measured no faster than 4 at 20 keyframes x 1300 edges: 22.1 against 21.1 us -- the keyframe's edges are
@@ -427,9 +494,9 @@ void ba_launch_index_pose_first(hipStream_t s, const unsigned* skey, int E, int 
 {
     hipLaunchKernelGGL(k_ix_pose_first, dim3(nblk((long long)E + 1, 256)), dim3(256), 0, s, skey, E, nfree, pose_first);
 }
-void ba_launch_backsub(hipStream_t s, const BaDev& D)
+void ba_launch_backsub(hipStream_t s, const BaDev& D, double lambda)
 {
-    if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub<BA_LM_LANES>, dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D);
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_backsub<BA_LM_LANES>, dim3(nblk((long long)BA_LM_LANES * D.L, 256)), dim3(256), 0, s, D, lambda);
 }
 void ba_launch_update(hipStream_t s, const BaDev& D, double* save_poses, double* save_points)
 {

@@ -253,6 +253,34 @@ print("ok")
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_rejected_trial_after_a_linearisation_without_hpl():
+    """From the second LM iteration on the landmark linearisation leaves Hpl unwritten (k_ba_lin_landmark MODE 2): the Schur
+    product, the reduced right-hand side and the back-substitution work from Z and ce.  A REJECTED trial needs Z for another
+    lambda, and the host rebuilds Hpl for it.  The synthetic graphs accept every trial, so a test switch rejects the first
+    trial of iteration 2; the run must repeat bit for bit what a build that always keeps Hpl (CCM_BA_KEEP_HPL=1) computes,
+    on a dense-solver graph and on a PCG graph."""
+    import subprocess, sys
+    code = r'''
+import hashlib, numpy as np
+from motioncheck_ccm_slam_amd import _lib, synth
+from motioncheck_ccm_slam_amd.optimizer import Optimizer
+ctx = _lib.Context(0)
+for kf, pts in ((60, 3000), (400, 30000)):
+    g = synth.gba_graph(n_kf=kf, n_points=pts, n_agents=3, seed=kf)
+    r = Optimizer.MapFusionGBA(g, 6, ctx=ctx)
+    assert r["trials"] == r["iterations_done"] + 1, (r["trials"], r["iterations_done"])
+    assert r["chi2_final"] < 0.1 * r["chi2_initial"]
+    print(hashlib.sha1(np.ascontiguousarray(r["poses"]).tobytes() + np.ascontiguousarray(r["points"]).tobytes()).hexdigest())
+'''
+    outs = []
+    for keep in ("0", "1"):
+        env = dict(os.environ, CCM_BA_TEST_REJECT_AT="2", CCM_BA_KEEP_HPL=keep, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        outs.append(out.stdout.split())
+    assert len(outs[0]) == 2 and outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("dense_max", ["0", "100000"])
 def test_sharded_gba_two_ranks_on_one_gpu(dense_max, tmp_path):
     """Multi-GPU global BA rehearsed on one GPU: two processes = two ranks, each keeps the landmarks of its range,

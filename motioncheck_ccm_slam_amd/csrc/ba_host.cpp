@@ -827,7 +827,9 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                         // of host time) goes to the side stream right after this trial's first chunk of PCG iterations has been
                         // launched, so the host enqueues it while the GPU is already iterating.
                         bool side_todo = PC.Aci && more_trials_planned;
+                        double inv_host_ms = 0;
                         auto start_inversion = [&]() -> int {
+                            auto ti0 = clk::now();
                             double* Aw = S.pcg_acw.as<double>();
                             if (copy_recorded) CCM_HIP(c, hipStreamWaitEvent(S.side, S.ev_copy, 0));
                             CCM_HIP(c, hipMemsetAsync(info_dev + 4, 0, 4, S.side));
@@ -843,6 +845,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                             CCM_HIP(c, hipEventRecord(S.ev_inv, S.side));
                             CCM_HIP(c, hipGetLastError());
                             coarse_pending = true; side_todo = false;
+                            inv_host_ms = secs(ti0, clk::now()) * 1e3;
                             return CCM_OK;
                         };
                         const int max_it = 40 * 8 + (int)std::min<long long>(n, 4000);
@@ -912,7 +915,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                         else if (status == 0) solved = true;
                         if (side_todo && (rc = start_inversion())) return rc;
                         res->pcg_iterations += itc;
-                        if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms, rel.res %.2e\n", itc, secs(t2, clk::now()) * 1e3, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)));
+                        if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms (host time of the side-stream enqueue %.3f), rel.res %.2e\n", itc, secs(t2, clk::now()) * 1e3, inv_host_ms, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)));
                         if (solved && ok2) CCM_HIP(c, hipMemcpyAsync(D.x, S.pcg_w.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
                         if (!solved) res->pcg_fallbacks++;
                     }

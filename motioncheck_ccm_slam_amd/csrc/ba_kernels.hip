@@ -306,6 +306,9 @@ __global__ __launch_bounds__(256) void k_ba_lin_pose_wave(BaDev D, double huber_
 // x_l = Dinv (b_l - sum_e Hpl_e^T x_p(e)) with Hpl_e = Z_e L^T (L L^T = Hll + lambda I, Z the trial's Schur operand): Dinv b_l = db and
 // Dinv L = L^-T, so x_l = db - L^-T sum_e Z_e^T x_p(e) -- read from the array the Schur product has just used, which lets the
 // linearisation drop Hpl (k_ba_lin_landmark MODE 2).
+// (The loads of Z stay lane by lane, 16 bytes each at a stride of 144: fetched as runs of G x 16 bytes and handed out through LDS -- the
+// mirror image of lm_store_group, which pays for the stores -- the kernel measured 99 instead of 90 us at config 5: a line that a lane's
+// nine loads touch is still in the L1 for the next of them.)
 template <int G>
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev D, double lambda)
 {

@@ -135,16 +135,39 @@ __global__ __launch_bounds__(256) void k_sp_dinv(BaDev D, double lambda)
 // are positive whenever the block is.)
 __global__ __launch_bounds__(256) void k_sp_edge_y(BaDev D, double lambda)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= D.E) return;
-    const int l = D.edge_point[e];
-    double f[6], Bx[18];
-    ba_chol3(D.Hll + 9 * (long long)l, lambda, f);               // (pivot guard: see ba_math.h)
-    const double* B = D.Hpl + 18 * (long long)e;
-    for (int i = 0; i < 18; i++) Bx[i] = B[i];
-    const double* d = D.db + 3 * (long long)l;
-    const double dd[3] = { d[0], d[1], d[2] };
-    ba_edge_z_c(Bx, f, dd, D.Z + 18 * (long long)e, D.ce + 6 * (long long)e);
+    // The workgroup's 256 blocks of Z (144 bytes each) and of ce (48) lie side by side: passed through LDS and stored as full lines
+    // instead of 16 bytes per lane at a stride of 144 (182 -> 112 us at config 5; the same remedy as lm_store_group in ba_kernels.hip).
+    __shared__ double2 stage[256 * 9];
+    const long long e0 = blockIdx.x * 256LL;
+    const long long e = e0 + threadIdx.x;
+    double zz[18], cc[6];
+    if (e < D.E) {
+        const int l = D.edge_point[e];
+        double f[6], Bx[18];
+        ba_chol3(D.Hll + 9 * (long long)l, lambda, f);               // (pivot guard: see ba_math.h)
+        const double2* B = reinterpret_cast<const double2*>(D.Hpl + 18 * e);
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const double2 v = B[i]; Bx[2 * i] = v.x; Bx[2 * i + 1] = v.y; }
+        const double* d = D.db + 3 * (long long)l;
+        const double dd[3] = { d[0], d[1], d[2] };
+        ba_edge_z_c(Bx, f, dd, zz, cc);
+#pragma unroll
+        for (int i = 0; i < 9; i++) stage[9 * threadIdx.x + i] = make_double2(zz[2 * i], zz[2 * i + 1]);
+    }
+    __syncthreads();
+    const int ne = (int)min(256LL, D.E - e0);
+    double2* zo = reinterpret_cast<double2*>(D.Z + 18 * e0);
+#pragma unroll
+    for (int j = 0; j < 9; j++) { const int q = j * 256 + threadIdx.x; if (q < 9 * ne) zo[q] = stage[q]; }
+    __syncthreads();
+    if (e < D.E) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) stage[3 * threadIdx.x + i] = make_double2(cc[2 * i], cc[2 * i + 1]);
+    }
+    __syncthreads();
+    double2* co = reinterpret_cast<double2*>(D.ce + 6 * e0);
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int q = j * 256 + threadIdx.x; if (q < 3 * ne) co[q] = stage[q]; }
 }
 
 // One workgroup per reduced-camera block: block = Hpp(diag) - sum over its sorted (landmark, pose pair) list of Z_a Z_b^T

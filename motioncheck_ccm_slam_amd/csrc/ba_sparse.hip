@@ -33,24 +33,62 @@ __global__ __launch_bounds__(256) void k_sp_pair_count(BaDev D, int* __restrict_
     cnt[l] = kf * (kf + 1) / 2;
 }
 
-// enumerate the pairs: key = f_a * nfree + f_b (f_a <= f_b because edges are sorted by pose), value = (ea, eb)
+// enumerate the pairs: key = f_a * nfree + f_b (f_a <= f_b because edges are sorted by pose), value = (ea, eb), in the order of a walk
+// through the landmark's triangle row by row.  SP_PF_LANES lanes per landmark: they collect the landmark's free edges in LDS (in edge
+// order, by ballot) and write the triangle's entries i = g, g + SP_PF_LANES, ... -- neighbouring lanes, neighbouring entries.  (One
+// thread per landmark left every lane of a wave storing into a region of its own, 46 entries apart at config 5: 260 us for 110 MB;
+// a lane per ROW of the triangle, re-reading the edges from global memory: 153 us.)  A landmark with more than SP_PF_CAP free edges
+// takes the row form.
+#define SP_PF_LANES 8
+#define SP_PF_CAP 48
 __global__ __launch_bounds__(256) void k_sp_pair_fill(BaDev D, const int* __restrict__ off, unsigned* __restrict__ key,
                                                       unsigned long long* __restrict__ val)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int2 fl[256 / SP_PF_LANES][SP_PF_CAP];
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int l = gt / SP_PF_LANES, g = gt - l * SP_PF_LANES;
     if (l >= D.L) return;
-    int p = off[l];
+    int2* mine = fl[threadIdx.x / SP_PF_LANES];
     const int e0 = D.pt_first[l], e1 = D.pt_first[l + 1];
+    const int shift = (threadIdx.x & 63) - g;                        // first lane of the group inside its wave
+    int kf = 0;
+    for (int eb = e0; eb < e1; eb += SP_PF_LANES) {                  // (the same trip count for the lanes of a group)
+        const int e = eb + g;
+        const int fr = e < e1 ? D.free_of[D.edge_pose[e]] : -1;
+        const unsigned gm = (unsigned)(__ballot(fr >= 0) >> shift) & ((1u << SP_PF_LANES) - 1u);
+        if (fr >= 0) {
+            const int pos = kf + __popc(gm & ((1u << g) - 1u));
+            if (pos < SP_PF_CAP) mine[pos] = make_int2(e, fr);
+        }
+        kf += __popc(gm);
+    }
+    const int base = off[l];
+    if (kf <= SP_PF_CAP) {
+        const int T = kf * (kf + 1) / 2;
+        int r = 0, row_start = 0, row_len = kf;
+        for (int i = g; i < T; i += SP_PF_LANES) {
+            while (i >= row_start + row_len) { row_start += row_len; row_len--; r++; }
+            const int2 ea = mine[r], eb2 = mine[r + (i - row_start)];
+            key[base + i] = (unsigned)ea.y * (unsigned)D.nfree + (unsigned)eb2.y;
+            val[base + i] = ((unsigned long long)(unsigned)ea.x << 32) | (unsigned)eb2.x;
+        }
+        return;
+    }
+    int r = 0;
     for (int a = e0; a < e1; a++) {
         const int fa = D.free_of[D.edge_pose[a]];
         if (fa < 0) continue;
-        for (int b = a; b < e1; b++) {
-            const int fb = D.free_of[D.edge_pose[b]];
-            if (fb < 0) continue;
-            key[p] = (unsigned)fa * (unsigned)D.nfree + (unsigned)fb;
-            val[p] = ((unsigned long long)(unsigned)a << 32) | (unsigned)b;
-            p++;
+        if (r % SP_PF_LANES == g) {
+            int p = base + r * kf - r * (r - 1) / 2;
+            for (int b = a; b < e1; b++) {
+                const int fb = D.free_of[D.edge_pose[b]];
+                if (fb < 0) continue;
+                key[p] = (unsigned)fa * (unsigned)D.nfree + (unsigned)fb;
+                val[p] = ((unsigned long long)(unsigned)a << 32) | (unsigned)b;
+                p++;
+            }
         }
+        r++;
     }
 }
 
@@ -1418,7 +1456,7 @@ hipError_t sp_sort_u32(hipStream_t s, void* tmp, size_t tmp_bytes, const unsigne
 
 void sp_launch_pair_count(hipStream_t s, const BaDev& D, int* cnt) { hipLaunchKernelGGL(k_sp_pair_count, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, cnt); }
 void sp_launch_pair_fill(hipStream_t s, const BaDev& D, const int* off, unsigned* key, unsigned long long* val)
-{ hipLaunchKernelGGL(k_sp_pair_fill, dim3(nblk(D.L, 256)), dim3(256), 0, s, D, off, key, val); }
+{ hipLaunchKernelGGL(k_sp_pair_fill, dim3(nblk((long long)SP_PF_LANES * D.L, 256)), dim3(256), 0, s, D, off, key, val); }
 void sp_launch_mark(hipStream_t s, const unsigned* key, long long np, int nfree, uint8_t* map)
 { const long long m = np > nfree ? np : nfree; hipLaunchKernelGGL(k_sp_mark, dim3(nblk(m, 256)), dim3(256), 0, s, key, np, nfree, map); }
 void sp_launch_block_coords(hipStream_t s, const uint8_t* map, const int* id, long long n2, int nfree, int* br, int* bc, int* diag)

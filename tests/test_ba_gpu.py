@@ -44,6 +44,19 @@ def test_gba_small_and_medium(ctx, oracle):
         assert np.isclose(r["chi2_final"], ref["chi2_final"], rtol=1e-8)
 
 
+def test_landmarks_with_long_observation_lists(ctx, oracle):
+    """Landmarks seen by up to 64 keyframes (60 of them free): the pair enumeration of the block structure keeps a landmark's
+    free edges in LDS up to 48 and takes another path beyond; the 8-lane landmark kernels make several trips per landmark."""
+    g = synth.local_ba_graph(n_free=60, n_fixed=4, n_points=400, max_obs=64, seed=11)
+    assert np.bincount(g["edge_point"]).max() > 56
+    r = Optimizer.LocalBundleAdjustmentClient(g, ctx=ctx)
+    ref = oracle.ba_solve(g, 5, float(np.float32(np.sqrt(5.991))), 10)
+    assert pose_delta(r["poses"], ref["poses"]).max() <= TOL
+    assert np.abs(r["points"] - ref["points"]).max() <= 1e-6
+    assert r["iterations_done"] == ref["iterations_done"] and r["trials"] == ref["trials"]
+    assert (r["outlier"] == ref["outlier"]).all()
+
+
 def test_edge_order_does_not_matter(ctx):
     """The library orders the observations by (landmark, keyframe) itself (sorted input is detected in one pass, anything else goes
     through a linear-time counting sort): a shuffled edge list must give bit-identical poses, points and the outlier flags of the

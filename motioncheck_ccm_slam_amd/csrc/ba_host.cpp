@@ -500,6 +500,23 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         CCM_HIP(c, hipMemcpyAsync(&nb, S.sp_id.as<int>() + n2, 4, hipMemcpyDeviceToHost, st));
         CCM_HIP(c, hipStreamSynchronize(st));
         CCM_RESERVE(c, S.blk_row, (size_t)nb * 4); CCM_RESERVE(c, S.blk_col, (size_t)nb * 4); CCM_RESERVE(c, S.diag_id, (size_t)nfree * 4);
+        {
+            // the scale columns of the prolongation: keyframe translations as they are now, and each aggregate's mean
+            const int A = pcg_coarse_agg_keyframes(nfree), nagg = pcg_coarse_aggregates(nfree);
+            std::vector<double> sv(3 * (size_t)nfree + 3 * (size_t)nagg, 0.0);
+            for (int f = 0; f < nfree; f++) for (int q = 0; q < 3; q++) sv[3 * (size_t)f + q] = pb->poses[7 * (size_t)pose_of_free[f] + 4 + q];
+            for (int I = 0; I < nagg; I++) {
+                const int f0 = I * A, f1 = std::min(nfree, f0 + A);
+                for (int q = 0; q < 3; q++) {
+                    double m = 0;
+                    for (int f = f0; f < f1; f++) m += sv[3 * (size_t)f + q];
+                    sv[3 * (size_t)nfree + 3 * I + q] = m / std::max(1, f1 - f0);
+                }
+            }
+            CCM_RESERVE(c, S.pcg_svec, sv.size() * 8 + 64);
+            CCM_HIP(c, hipMemcpyAsync(S.pcg_svec.p, sv.data(), sv.size() * 8, hipMemcpyHostToDevice, st));
+            CCM_HIP(c, hipStreamSynchronize(st));                                                         // sv is a local (the stream is idle here: nb has just been read)
+        }
         sp_launch_block_coords(st, S.sp_map.as<uint8_t>(), S.sp_id.as<int>(), n2, nfree, S.blk_row.as<int>(), S.blk_col.as<int>(), S.diag_id.as<int>());
         // this rank's pairs sorted by target block (stable: fixed summation order)
         const size_t sort_tmp = sp_sort_temp_bytes((size_t)std::max<long long>(NP, 2LL * nb));
@@ -529,21 +546,6 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
             CCM_RESERVE(c, S.pcg_aci, ncp * ncp * 8 + 64); CCM_RESERVE(c, S.pcg_acw, (ncp * ncp + 48 * 48) * 8 + 64);   // + one block of scratch
             const size_t nrp = ((size_t)n / 192 + 2) * 4 * 7;                                                     // block partials of P^T r (ba_sparse.hip: PCG_UPD_TPB, PCG_RSLOTS, PCG_CDOF)
             CCM_RESERVE(c, S.pcg_coarse, (nrp + nc + (size_t)pcg_coarse_parts(nfree) + 64) * 8);                // P^T r, yc, cpart
-            // the scale columns of the prolongation: keyframe translations as they are now, and each aggregate's mean
-            const int A = pcg_coarse_agg_keyframes(nfree), nagg = pcg_coarse_aggregates(nfree);
-            std::vector<double> sv(3 * (size_t)nfree + 3 * (size_t)nagg, 0.0);
-            for (int f = 0; f < nfree; f++) for (int q = 0; q < 3; q++) sv[3 * (size_t)f + q] = pb->poses[7 * (size_t)pose_of_free[f] + 4 + q];
-            for (int I = 0; I < nagg; I++) {
-                const int f0 = I * A, f1 = std::min(nfree, f0 + A);
-                for (int q = 0; q < 3; q++) {
-                    double m = 0;
-                    for (int f = f0; f < f1; f++) m += sv[3 * (size_t)f + q];
-                    sv[3 * (size_t)nfree + 3 * I + q] = m / std::max(1, f1 - f0);
-                }
-            }
-            CCM_RESERVE(c, S.pcg_svec, sv.size() * 8 + 64);
-            CCM_HIP(c, hipMemcpyAsync(S.pcg_svec.p, sv.data(), sv.size() * 8, hipMemcpyHostToDevice, st));
-            CCM_HIP(c, hipStreamSynchronize(st));                                                         // sv is a local
         }
         CCM_HIP(c, hipGetLastError());
     }
@@ -576,19 +578,6 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         PC.cpart = PC.yc + nc;
         PC.svec = S.pcg_svec.as<double>();
         PC.cen = PC.svec + 3 * (size_t)nfree;
-        // the aggregate pairs that hold a block (the grid of the coarse matrix's assembly): fixed for the call
-        const int nagg = pcg_coarse_aggregates(nfree);
-        CCM_RESERVE(c, S.pcg_aggmap, (size_t)nagg * nagg + 16);
-        CCM_HIP(c, hipMemsetAsync(S.pcg_aggmap.p, 0, (size_t)nagg * nagg, st));
-        pcg_launch_coarse_mark(st, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, nfree, S.pcg_aggmap.as<uint8_t>());
-        std::vector<uint8_t> am((size_t)nagg * nagg);
-        CCM_HIP(c, hipMemcpyAsync(am.data(), S.pcg_aggmap.p, am.size(), hipMemcpyDeviceToHost, st));
-        CCM_HIP(c, hipStreamSynchronize(st));
-        for (int I = 0; I < nagg; I++)
-            for (int J = I; J < nagg; J++) if (am[(size_t)I * nagg + J]) { coarse_pairs.push_back(I); coarse_pairs.push_back(J); }
-        CCM_RESERVE(c, S.pcg_pairs, coarse_pairs.size() * 4 + 16);
-        CCM_HIP(c, hipMemcpyAsync(S.pcg_pairs.p, coarse_pairs.data(), coarse_pairs.size() * 4, hipMemcpyHostToDevice, st));
-        CCM_HIP(c, hipStreamSynchronize(st));
     }
     // Which iteration: the pipelined one (two kernels per iteration, ba_sparse.hip) for the tolerances a BA asks for; its recurrences
     // stall near a relative residual of 1e-9, so a caller that wants more than 1e-7 gets the classic four-kernel iteration.
@@ -615,17 +604,19 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     hipGraph_t pcg_graph[4] = {nullptr, nullptr, nullptr, nullptr}; hipGraphExec_t pcg_exec[4] = {nullptr, nullptr, nullptr, nullptr};
     struct GraphGuard { hipGraph_t* g; hipGraphExec_t* e; ~GraphGuard() { for (int i = 0; i < 4; i++) { if (e[i]) (void)hipGraphExecDestroy(e[i]); if (g[i]) (void)hipGraphDestroy(g[i]); } } } graph_guard{pcg_graph, pcg_exec};
     lap("block structure (pairs, sort)");
-    if (use_pcg && nfree > 0) {
-        CCM_HIP(c, hipStreamSynchronize(st));
+    // (Captured on the context's second auxiliary stream, which is idle, while the main stream is still sorting the pair lists: the 0.3 ms
+    //  of host time the capture takes used to be idle time of the GPU.)
+    hipStream_t cap_st = (use_pcg && nfree > 0) ? ccm_aux_stream(c, 1) : nullptr;
+    if (cap_st) {
         for (int gi = 0; gi < (PC.Aci ? 4 : 2); gi++) {
             const PcgCoarse& pc = (gi >> 1) ? PC : PC0;
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            if (hipStreamBeginCapture(cap_st, hipStreamCaptureModeRelaxed) == hipSuccess) {
                 for (int k = 0; k < pcg_len[gi & 1]; k++) {
-                    if (pipelined) ppcg_launch_iter(st, S.Minv.as<double>(), S.row_ptr.as<int>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pc, PB);
-                    else pcg_launch_iter(st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
+                    if (pipelined) ppcg_launch_iter(cap_st, S.Minv.as<double>(), S.row_ptr.as<int>(), nfree, S.pcg_w.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), pc, PB);
+                    else pcg_launch_iter(cap_st, Hb, S.row_ptr.as<int>(), S.ent_key2.as<unsigned>(), S.ent_val2.as<unsigned>(), S.Minv.as<double>(),
                                          nfree, S.pcg_w.as<double>(), S.pcg_pap.as<double>(), S.pcg_part.as<double>(), S.pcg_sc.as<double>(), k & 1, pc);
                 }
-                hipError_t e1 = hipStreamEndCapture(st, &pcg_graph[gi]);
+                hipError_t e1 = hipStreamEndCapture(cap_st, &pcg_graph[gi]);
                 hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&pcg_exec[gi], pcg_graph[gi], nullptr, nullptr, 0) : e1;
                 if (e2 != hipSuccess) {
                     pcg_exec[gi] = nullptr;                     // fall back to plain launches
@@ -649,6 +640,21 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
             hipError_t e2 = e1 == hipSuccess ? hipGraphInstantiate(&inv_exec, inv_graph, nullptr, nullptr, 0) : e1;
             if (e2 != hipSuccess) { inv_exec = nullptr; (void)hipGetLastError(); }
         } else (void)hipGetLastError();
+    }
+    if (PC.Aci) {
+        // the aggregate pairs that hold a block (the grid of the coarse matrix's assembly): fixed for the call
+        const int nagg = pcg_coarse_aggregates(nfree);
+        CCM_RESERVE(c, S.pcg_aggmap, (size_t)nagg * nagg + 16);
+        CCM_HIP(c, hipMemsetAsync(S.pcg_aggmap.p, 0, (size_t)nagg * nagg, st));
+        pcg_launch_coarse_mark(st, S.blk_row.as<int>(), S.blk_col.as<int>(), nb, nfree, S.pcg_aggmap.as<uint8_t>());
+        std::vector<uint8_t> am((size_t)nagg * nagg);
+        CCM_HIP(c, hipMemcpyAsync(am.data(), S.pcg_aggmap.p, am.size(), hipMemcpyDeviceToHost, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
+        for (int I = 0; I < nagg; I++)
+            for (int J = I; J < nagg; J++) if (am[(size_t)I * nagg + J]) { coarse_pairs.push_back(I); coarse_pairs.push_back(J); }
+        CCM_RESERVE(c, S.pcg_pairs, coarse_pairs.size() * 4 + 16);
+        CCM_HIP(c, hipMemcpyAsync(S.pcg_pairs.p, coarse_pairs.data(), coarse_pairs.size() * 4, hipMemcpyHostToDevice, st));
+        CCM_HIP(c, hipStreamSynchronize(st));
     }
     lap("PCG graph capture");
     if (split_up) CCM_HIP(c, hipStreamWaitEvent(st, S.ev_up, 0));          // observations, information values, points have arrived

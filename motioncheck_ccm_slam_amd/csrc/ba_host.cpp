@@ -1036,14 +1036,17 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     }
     if (outlier_out) {
         ba_launch_pose_rt(st, D);
-        std::vector<uint8_t> fl(std::max(E, 1));
+        const bool straight = ranks == 1 && direct;               // the caller's array is in the device's edge order
+        std::vector<uint8_t> fl(straight ? 1 : std::max(E, 1));
         if (E > 0) {
             ba_launch_outliers(st, D, opt->outlier_chi2, S.flags.as<uint8_t>());
-            CCM_HIP(c, hipMemcpyAsync(fl.data(), S.flags.p, E, hipMemcpyDeviceToHost, st));
+            CCM_HIP(c, hipMemcpyAsync(straight ? outlier_out : fl.data(), S.flags.p, E, hipMemcpyDeviceToHost, st));
         }
         CCM_HIP(c, hipStreamSynchronize(st));
-        if (ranks == 1) {
-            for (int k = 0; k < E; k++) outlier_out[direct ? k : perm[k]] = fl[k];
+        if (straight) {
+            // (downloaded in place)
+        } else if (ranks == 1) {
+            for (int k = 0; k < E; k++) outlier_out[perm[k]] = fl[k];
         } else {
             // flags of the other ranks' edges: exchange as doubles through the same collective
             std::vector<double> full(Eall, 0.0);

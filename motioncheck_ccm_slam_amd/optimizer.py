@@ -33,24 +33,62 @@ def _stop_flag_view(stop_flag):
     return stop_flag.view(np.uint8)
 
 
-def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None, pcg_tol=0.0):
+class BaWorkspace:
+    """Page-locked in/out arrays for the keyframe poses and the map points, kept by a caller that optimises maps again and again (a
+    server's GBA thread): ccm_ba_solve reads the start values from and writes the results to the caller's own arrays, and a copy
+    between the GPU and freshly allocated pageable memory costs several times what the PCIe transfer does (config 5: 0.9 ms for the
+    4.9 MB of results).  A solve that is given a workspace copies the graph's start values into it and returns VIEWS of it: they are
+    overwritten by the next solve with the same workspace."""
+
+    def __init__(self, ctx, n_poses: int, n_points: int):
+        self.ctx = ctx
+        self.poses = np.empty((max(int(n_poses), 1), 7), "f8")
+        self.points = np.empty((max(int(n_points), 1), 3), "f8")
+        ctx.host_register(self.poses)
+        ctx.host_register(self.points)
+        self._open = True
+
+    def close(self):
+        if self._open:
+            self._open = False
+            self.ctx.host_unregister(self.poses)
+            self.ctx.host_unregister(self.points)
+
+    def take(self, poses, points):
+        poses = np.asarray(poses, "f8").reshape(-1, 7); points = np.asarray(points, "f8").reshape(-1, 3)
+        if len(poses) > len(self.poses) or len(points) > len(self.points):
+            raise ValueError("BaWorkspace holds %d poses / %d points, the graph has %d / %d"
+                             % (len(self.poses), len(self.points), len(poses), len(points)))
+        a = self.poses[:len(poses)]; b = self.points[:len(points)]
+        np.copyto(a, poses); np.copyto(b, points)
+        return a, b
+
+
+def _solve(ctx, graph, iterations, huber, iterations2=0, stop_flag=None, pcg_tol=0.0, want_outliers=False, workspace=None):
+    """want_outliers: the per-edge chi2 / depth test on the final state, which only LocalBundleAdjustmentClient uses
+    (src/Optimizer.cpp:577-595); the global entry points leave `edge_outlier` NULL like the shim (shim/cslam_optimizer.cpp) -- the
+    test is another pass over the edges and 1 byte per edge back to the host."""
     lib = _lib.load()
+    if workspace is not None:
+        poses0, points0 = workspace.take(graph["poses"], graph["points"])
+    else:
+        poses0 = np.ascontiguousarray(graph["poses"], "f8").copy(); points0 = np.ascontiguousarray(graph["points"], "f8").copy()
     keep = dict(
-        poses=np.ascontiguousarray(graph["poses"], "f8").copy(), fixed=np.ascontiguousarray(graph["fixed"], np.uint8),
-        intr=np.ascontiguousarray(graph["intr"], "f8"), points=np.ascontiguousarray(graph["points"], "f8").copy(),
+        poses=poses0, fixed=np.ascontiguousarray(graph["fixed"], np.uint8),
+        intr=np.ascontiguousarray(graph["intr"], "f8"), points=points0,
         edge_pose=np.ascontiguousarray(graph["edge_pose"], "i4"), edge_point=np.ascontiguousarray(graph["edge_point"], "i4"),
         obs=np.ascontiguousarray(graph["obs"], "f8"), info=np.ascontiguousarray(graph["info"], "f8"))
     p = _lib.ptr
     pb = BaProblem(len(keep["poses"]), p(keep["poses"]), p(keep["fixed"]), p(keep["intr"]),
                    len(keep["points"]), p(keep["points"]), len(keep["edge_pose"]),
                    p(keep["edge_pose"]), p(keep["edge_point"]), p(keep["obs"]), p(keep["info"]))
-    outl = np.zeros(max(len(keep["edge_pose"]), 1), np.uint8)
+    outl = np.zeros(max(len(keep["edge_pose"]), 1), np.uint8) if want_outliers else None
     flag = _stop_flag_view(stop_flag)
     opt = BaOptions(int(iterations), float(huber), int(iterations2), CHI2_MONO, p(flag), float(pcg_tol))
     res = BaResult()
-    res.edge_outlier = p(outl)
+    res.edge_outlier = p(outl) if want_outliers else None
     ctx.check(lib.ccm_ba_solve(ctx.handle, C.byref(pb), C.byref(opt), C.byref(res)))
-    return dict(poses=keep["poses"], points=keep["points"], outlier=outl[:len(keep["edge_pose"])],
+    return dict(poses=keep["poses"], points=keep["points"], outlier=outl[:len(keep["edge_pose"])] if want_outliers else None,
                 iterations_done=res.iterations_done, trials=res.trials, chi2_initial=res.chi2_initial,
                 chi2_final=res.chi2_final, lambda_final=res.lambda_final, stopped=bool(res.stopped),
                 t_linearize=res.t_linearize, t_schur=res.t_schur, t_solve=res.t_solve, t_update=res.t_update,
@@ -62,9 +100,9 @@ class Optimizer:
     """Static-method style like the reference; `ctx` selects the GPU context (default: device 0)."""
 
     @staticmethod
-    def BundleAdjustmentClient(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None):
+    def BundleAdjustmentClient(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None, workspace=None):
         ctx = ctx or _lib.default_context(0)
-        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag)
+        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag, workspace=workspace)
 
     GlobalBundleAdjustemntClient = BundleAdjustmentClient      # [sic] the reference's spelling, Optimizer.h:86
 
@@ -72,12 +110,12 @@ class Optimizer:
     def LocalBundleAdjustmentClient(graph, pbStopFlag=None, ctx=None):
         """5 robust iterations, outlier relabelling, 10 more without kernels (src/Optimizer.cpp:536-568)."""
         ctx = ctx or _lib.default_context(0)
-        return _solve(ctx, graph, 5, TH_HUBER_2D_LOCAL, 10, pbStopFlag)
+        return _solve(ctx, graph, 5, TH_HUBER_2D_LOCAL, 10, pbStopFlag, want_outliers=True)
 
     @staticmethod
-    def MapFusionGBA(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None, pcg_tol: float = 0.0):
+    def MapFusionGBA(graph, nIterations: int = 5, pbStopFlag=None, bRobust: bool = True, ctx=None, pcg_tol: float = 0.0, workspace=None):
         ctx = ctx or _lib.default_context(0)
-        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag, pcg_tol)
+        return _solve(ctx, graph, nIterations, TH_HUBER_2D_GLOBAL if bRobust else 0.0, 0, pbStopFlag, pcg_tol, workspace=workspace)
 
 
     @staticmethod

@@ -921,7 +921,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                         else if (status == 0) solved = true;
                         if (side_todo && (rc = start_inversion())) return rc;
                         res->pcg_iterations += itc;
-                        if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms (host time of the side-stream enqueue %.3f), rel.res %.2e\n", itc, secs(t2, clk::now()) * 1e3, inv_host_ms, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)));
+                        if (getenv("CCM_DEBUG")) fprintf(stderr, "[ccm] PCG trial: %d iterations, %.3f ms (host time of the side-stream enqueue %.3f), rel.res %.2e, |b| %.4e, lambda %.3e\n", itc, secs(t2, clk::now()) * 1e3, inv_host_ms, std::sqrt(sc[2] / std::max((double)sc[1], 1e-300)), std::sqrt((double)sc[1]), lambda);
                         if (solved && ok2) CCM_HIP(c, hipMemcpyAsync(D.x, S.pcg_w.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
                         if (!solved) res->pcg_fallbacks++;
                     }

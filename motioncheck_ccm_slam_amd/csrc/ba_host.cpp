@@ -87,6 +87,7 @@ void ba_launch_index_pose_first(hipStream_t, const unsigned* skey, int E, int nf
 void ba_launch_update(hipStream_t, const BaDev&, double* save_poses, double* save_points);
 int ba_scale_blocks(const BaDev&);
 void ba_launch_scale(hipStream_t, const BaDev&, double lambda, int add_pose_lambda, double* partial, double* out);
+void ba_launch_errors_scale(hipStream_t, const BaDev&, double hd, double lambda, int add_pose_lambda, double* partial, double* out);
 void ba_launch_diag(hipStream_t, const BaDev&, double* tmp_ll, double* pp_diag, double* out_ll_max);
 void ba_launch_outliers(hipStream_t, const BaDev&, double th, uint8_t* flag);
 void ba_launch_deactivate(hipStream_t, const BaDev&, const uint8_t* flag);
@@ -450,7 +451,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     CCM_RESERVE(c, S.Hpl, std::max<size_t>(18 * (size_t)E * 8, 16)); CCM_RESERVE(c, S.Dinv, std::max<size_t>(9 * (size_t)L * 8, 16));
     CCM_RESERVE(c, S.x, std::max<size_t>(nxl * 8, 16));
     CCM_RESERVE(c, S.save_poses, 7 * (size_t)P * 8); CCM_RESERVE(c, S.save_points, std::max<size_t>(3 * (size_t)L * 8, 16));
-    const size_t nb_max = (size_t)std::max((E + 255) / 256, (int)((nxl + 255) / 256)) + 8;
+    const size_t nb_max = (size_t)(E + 255) / 256 + (nxl + 255) / 256 + 8;             // (ba_launch_errors_scale keeps both kernels' partial sums)
     CCM_RESERVE(c, S.partial, nb_max * 8); CCM_RESERVE(c, S.scal, 64 * 8); CCM_RESERVE(c, S.info_dev, 64);
     CCM_RESERVE(c, S.tmp_ll, std::max<size_t>((size_t)L * 8, 16)); CCM_RESERVE(c, S.pp_diag, std::max<size_t>((size_t)n * 8, 16));
     CCM_HIP(c, hipMemsetAsync(S.active.p, 1, std::max(E, 1), st));
@@ -681,9 +682,9 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     // chi2 (+ optionally scale) of the current state, summed over ranks
     auto eval_chi2 = [&](double hd, bool with_scale, double lambda, double* chi, double* scale, bool rt_current = false) -> int {
         if (!rt_current) ba_launch_pose_rt(st, D);                             // (k_ba_update leaves the matrices of the poses it moved)
-        if (E > 0) ba_launch_errors(st, D, hd, partial, scal);
+        if (with_scale) ba_launch_errors_scale(st, D, hd, lambda, rank == 0 ? 1 : 0, partial, scal);
+        else if (E > 0) ba_launch_errors(st, D, hd, partial, scal);
         else CCM_HIP(c, hipMemsetAsync(scal, 0, 8, st));
-        if (with_scale) ba_launch_scale(st, D, lambda, rank == 0 ? 1 : 0, partial, scal + 1);
         if (ranks > 1) {
             if (!with_scale) CCM_HIP(c, hipMemsetAsync(scal + 1, 0, 8, st));
             S.pinned[13] = (opt->stop_flag && *opt->stop_flag) ? 1.0 : 0.0;

@@ -79,6 +79,33 @@ __global__ __launch_bounds__(256) void k_ba_reduce(const double* __restrict__ in
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// the sums of TWO arrays in one launch (block 0: in0 -> out0, block 1: in1 -> out1), each in k_ba_reduce's order: a trial's chi2 and
+// its gain denominator are needed together, and a launch of their own each was 5 us of a launch-bound local BA's trial
+__global__ __launch_bounds__(256) void k_ba_reduce2(const double* __restrict__ in0, int n0, double* __restrict__ out0,
+                                                    const double* __restrict__ in1, int n1, double* __restrict__ out1)
+{
+    __shared__ double red[256];
+    const double* __restrict__ in = blockIdx.x ? in1 : in0;
+    const int n = blockIdx.x ? n1 : n0;
+    double acc = 0.0;
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = in[i + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = acc + v[q];
+    }
+    for (; i < n; i += 256) acc = acc + in[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) (blockIdx.x ? out1 : out0)[0] = red[0];
+}
+
 // G lanes per landmark (G = BA_LM_LANES = 8 on every map size): accumulate Hll (full 3x3) and b_l over its edges, store Hpl = w B^T A per edge.
 // Lane g walks every G-th edge of the landmark; the G partial sums are added pairwise by xor-shuffles (a fixed tree: reproducible).
 // One thread per landmark was eight dependent rounds of f64 latency on a landmark of eight observations, and a local BA's 5000
@@ -507,6 +534,14 @@ void ba_launch_update(hipStream_t s, const BaDev& D, double* save_poses, double*
     if (n > 0) hipLaunchKernelGGL(k_ba_update, dim3(nblk(n, 256)), dim3(256), 0, s, D, save_poses, save_points);
 }
 int ba_scale_blocks(const BaDev& D) { return nblk(6LL * D.nfree + 3LL * D.L, 256); }
+// chi2 of the state after the update (-> out[0]) and the trial's gain denominator (-> out[1]); partial: room for both kernels' blocks
+void ba_launch_errors_scale(hipStream_t s, const BaDev& D, double hd, double lambda, int add_pose_lambda, double* partial, double* out)
+{
+    const int nbe = nblk(D.E, 256), nbs = ba_scale_blocks(D);
+    if (nbe > 0) hipLaunchKernelGGL(k_ba_errors, dim3(nbe), dim3(256), 0, s, D, hd, partial);
+    if (nbs > 0) hipLaunchKernelGGL(k_ba_scale, dim3(nbs), dim3(256), 0, s, D, lambda, add_pose_lambda, partial + nbe);
+    hipLaunchKernelGGL(k_ba_reduce2, dim3(2), dim3(256), 0, s, (const double*)partial, nbe, out, (const double*)(partial + nbe), nbs, out + 1);
+}
 void ba_launch_scale(hipStream_t s, const BaDev& D, double lambda, int add_pose_lambda, double* partial, double* out)
 {
     const int nb = ba_scale_blocks(D);

@@ -1627,15 +1627,18 @@ void ppcg_launch_publish(hipStream_t s, const double* part, int nfree, double* s
 // factorisation and both triangular solves.  The block Gauss-Jordan path below needs ~14 launches for such a system and took
 // 0.5 ms per LM trial -- 70 % of the whole local BA.  n <= DENSE_SMALL_MAX so that every tile of the lower triangle has its thread.
 #define DENSE_SMALL_MAX 138
-#define DS_TPB 320
-// Every 6x6 tile of the lower triangle lives in the REGISTERS of one thread for the whole solve (n <= 138: at most 276 tiles):
-// per block column the diagonal tile's owner factors it and publishes it in LDS, the owners of the tiles below solve against it
-// (multiplying by the reciprocals of its diagonal: a double-precision division is ~12 instructions, 36 of them per tile and column
-// were a fifth of the kernel) and publish the panel, every remaining tile subtracts panel_I panel_K^T from its registers -- two
-// barriers per block column, and the only LDS traffic is the panel and the right-hand side.  The forward substitution rides along
-// with the factorisation and the backward one reads the factor from the registers it already is in, so the factor is never written
-// anywhere.  (History at n = 120: matrix in LDS column by column 256 us, blocked in LDS 133 us, register tiles + the factor copied
-// to LDS for two separate substitution loops 116 us.)
+#define DS_TPB 576
+// Every 6x6 tile of the lower triangle lives in the REGISTERS of TWO neighbouring threads for the whole solve, three rows each
+// (n <= 138: at most 276 tiles, 552 threads): per block column the diagonal tile's owners factor it and publish it in LDS, the owners
+// of the tiles below solve against it (multiplying by the reciprocals of its diagonal: a double-precision division is ~12
+// instructions, 36 of them per tile and column were a fifth of the kernel) and publish the panel, every remaining tile subtracts
+// panel_I panel_K^T from its registers -- two barriers per block column, and the only LDS traffic is the panel and the right-hand
+// side.  The forward substitution rides along with the factorisation and the backward one reads the factor from the registers it
+// already is in, so the factor is never written anywhere.  (History at n = 120: matrix in LDS column by column 256 us, blocked in LDS
+// 133 us, register tiles + the factor copied to LDS for two separate substitution loops 116 us, one thread per tile 88 us: the
+// kernel is bound by the double-precision instructions its busiest thread issues per block column -- 216 multiply-adds of a trailing
+// tile, now 108 -- not by anything a second workgroup could share.)  The two owners of a diagonal tile exchange their rows by
+// shuffles and BOTH run the serial 6 x 6 factorisation, so neither waits for the other's result.
 // The damping is added to the diagonal while the tiles are loaded and the verdict is WRITTEN (0 / 1) rather than or-ed in: the
 // launches of k_sp_add_lambda and of the memset of `bad` in front of this kernel were two of a local BA trial's thirteen.
 __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __restrict__ Hb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
@@ -1655,54 +1658,70 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
     __syncthreads();
     for (int k = tid; k < nb; k += DS_TPB) { const int r = blk_row[k], c = blk_col[k]; if (r <= c && c < nbk) s_tile_blk[c * (c + 1) / 2 + r] = k; }
     __syncthreads();
-    // tile (I, K), K <= I, of thread tid
+    // rows 3 p .. 3 p + 2 of tile (I, K), K <= I
+    const int tile = tid >> 1, p = tid & 1;
     int I = 0, K = 0;
-    const bool have = tid < ntiles;
-    if (have) { while ((I + 1) * (I + 2) / 2 <= tid) I++; K = tid - I * (I + 1) / 2; }
-    double T[6][6];
+    const bool have = tile < ntiles;
+    // tiles in COLUMN-major order (block column K, then block row I): the tiles still at work in step J -- K >= J -- are the tail of
+    // the thread range, so the waves in front of it skip a step's phases altogether instead of issuing them for one or two live lanes
+    // (row-major order kept every wave busy until the last columns: 79.6 against 68.2 us at n = 120)
+    if (have) { int t = tile; while (t >= nbk - K) { t -= nbk - K; K++; } I = K + t; }
+    const int tile_rm = I * (I + 1) / 2 + K;                                 // its index in s_tile_blk (row-major)
+    double T[3][6];
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int k = 0; k < 6; k++) T[i][k] = 0.0;
-    if (have && s_tile_blk[tid] >= 0) {
-        const double* B = Hb + 36LL * s_tile_blk[tid];                       // stored block (row K, col I): tile(i, k) = B[k][i]
+    if (have && s_tile_blk[tile_rm] >= 0) {
+        const double* B = Hb + 36LL * s_tile_blk[tile_rm];                   // stored block (row K, col I): tile(i, k) = B[k][i]
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+        for (int ii = 0; ii < 3; ii++) {
+            const int i = 3 * p + ii;
 #pragma unroll
-            for (int k = 0; k < 6; k++) T[i][k] = B[k * 6 + i];
-        if (I == K) {                                                        // a diagonal block is stored whole; keep it exactly symmetric (upper half wins)
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int k = 0; k < i; k++) T[i][k] = T[k][i];
-#pragma unroll
-            for (int i = 0; i < 6; i++) T[i][i] += lambda;
+            for (int k = 0; k < 6; k++) {
+                // a diagonal block is stored whole; keep it exactly symmetric (upper half wins)
+                T[ii][k] = (I == K) ? B[max(i, k) * 6 + min(i, k)] : B[k * 6 + i];
+                if (I == K && k == i) T[ii][k] += lambda;
+            }
         }
     }
-    double dinv[6] = { 0, 0, 0, 0, 0, 0 };                                   // a diagonal tile's owner: 1 / L_cc
-    // factorisation, with the forward substitution L y = b riding along: the diagonal tile's owner solves its six unknowns as soon
-    // as the tile is factored, and the owner of panel tile (I, J) takes its product with y_J off b_I when the tile is final
-    // (one writer per block row and step).  Two barriers per block column.
+    // the full diagonal tile out of its two owners' rows (both owners call this together: they are neighbouring lanes of one wave)
+    auto gather_diag = [&](double (&F)[6][6]) {
+#pragma unroll
+        for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const double mine = T[ii][k], other = __shfl_xor(mine, 1, 64);
+                F[ii][k] = p ? other : mine;
+                F[3 + ii][k] = p ? mine : other;
+            }
+    };
+    double dinv[6] = { 0, 0, 0, 0, 0, 0 };                                   // a diagonal tile's owners: 1 / L_cc
+    // factorisation, with the forward substitution L y = b riding along: the diagonal tile's owners solve its six unknowns as soon
+    // as the tile is factored, and the owner of a panel tile's row takes its product with y_J off b_I when the row is final
+    // (one writer per unknown and step).  Two barriers per block column.
     for (int J = 0; J < nbk; J++) {
         const int j0 = 6 * J;
-        if (have && I == J && K == J) {                                      // 6x6 Cholesky of the diagonal tile
+        if (have && I == J && K == J) {                                      // 6x6 Cholesky of the diagonal tile, by both owners alike
+            double F[6][6];
+            gather_diag(F);
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                double d = T[c][c];
+                double d = F[c][c];
 #pragma unroll
-                for (int k = 0; k < c; k++) d -= T[c][k] * T[c][k];
+                for (int k = 0; k < c; k++) d -= F[c][k] * F[c][k];
                 if (!(d > 0.0)) { s_bad = 1; d = 1.0; }
                 // 1 / sqrt(d) once, sqrt(d) = d / sqrt(d): a square root AND a division per pivot were two ~25-instruction sequences on the
-                // one thread every other thread waits for (a third of the kernel)
+                // threads every other thread waits for (a third of the kernel)
                 const double id = rsqrt(d);
-                T[c][c] = d * id;
+                F[c][c] = d * id;
                 dinv[c] = id;
 #pragma unroll
                 for (int r = c + 1; r < 6; r++) {
-                    double w = T[r][c];
+                    double w = F[r][c];
 #pragma unroll
-                    for (int k = 0; k < c; k++) w -= T[r][k] * T[c][k];
-                    T[r][c] = w * id;
+                    for (int k = 0; k < c; k++) w -= F[r][k] * F[c][k];
+                    F[r][c] = w * id;
                 }
             }
             double y[6];
@@ -1710,14 +1729,24 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
             for (int c = 0; c < 6; c++) {
                 double w = v[j0 + c];
 #pragma unroll
-                for (int k = 0; k < c; k++) w -= T[c][k] * y[k];
+                for (int k = 0; k < c; k++) w -= F[c][k] * y[k];
                 y[c] = w * dinv[c];
             }
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
+            for (int i = 0; i < 6; i++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) { if (k > i) T[i][k] = 0.0; s_ljj[i * 6 + k] = T[i][k]; }
-                s_linv[i] = dinv[i]; s_y[i] = y[i]; v[j0 + i] = y[i];
+                for (int k = 0; k < 6; k++) if (k > i) F[i][k] = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) T[ii][k] = p ? F[3 + ii][k] : F[ii][k];
+            if (p == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s_ljj[i * 6 + k] = F[i][k];
+                    s_linv[i] = dinv[i]; s_y[i] = y[i]; v[j0 + i] = y[i];
+                }
             }
         }
         __syncthreads();
@@ -1730,7 +1759,7 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
                 for (int k = 0; k < i; k++) lj[i][k] = s_ljj[i * 6 + k];
             }
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+            for (int r = 0; r < 3; r++)
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
                     double w = T[r][c];
@@ -1739,27 +1768,32 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
                     T[r][c] = w * li[c];
                 }
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
+            for (int ii = 0; ii < 3; ii++) {
+                const int i = 3 * p + ii;
 #pragma unroll
-                for (int k = 0; k < 6; k++) s_panel[I][i * 6 + k] = T[i][k];
-                v[6 * I + i] -= ((T[i][0] * yj[0] + T[i][1] * yj[1]) + (T[i][2] * yj[2] + T[i][3] * yj[3])) + (T[i][4] * yj[4] + T[i][5] * yj[5]);
+                for (int k = 0; k < 6; k++) s_panel[I][i * 6 + k] = T[ii][k];
+                v[6 * I + i] -= ((T[ii][0] * yj[0] + T[ii][1] * yj[1]) + (T[ii][2] * yj[2] + T[ii][3] * yj[3])) + (T[ii][4] * yj[4] + T[ii][5] * yj[5]);
             }
         }
         __syncthreads();
         if (have && K > J) {                                                 // trailing tile: T -= panel_I panel_K^T
-            double pi[6][6], pk[6][6];
+            double pi[3][6], pk[6][6];
+#pragma unroll
+            for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) pi[ii][k] = s_panel[I][(3 * p + ii) * 6 + k];
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) { pi[i][k] = s_panel[I][i * 6 + k]; pk[i][k] = s_panel[K][i * 6 + k]; }
+                for (int k = 0; k < 6; k++) pk[i][k] = s_panel[K][i * 6 + k];
 #pragma unroll
-            for (int i = 0; i < 6; i++)
+            for (int ii = 0; ii < 3; ii++)
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     double w = 0;
 #pragma unroll
-                    for (int q = 0; q < 6; q++) w += pi[i][q] * pk[k][q];
-                    T[i][k] -= w;
+                    for (int q = 0; q < 6; q++) w += pi[ii][q] * pk[k][q];
+                    T[ii][k] -= w;
                 }
         }
     }
@@ -1768,16 +1802,19 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
     for (int J = nbk - 1; J >= 0; J--) {
         const int j0 = 6 * J;
         if (have && I == J && K == J) {
-            double xx[6];
+            double F[6][6], xx[6];
+            gather_diag(F);
 #pragma unroll
             for (int c = 5; c >= 0; c--) {
                 double w = v[j0 + c];
 #pragma unroll
-                for (int k = c + 1; k < 6; k++) w -= T[k][c] * xx[k];
+                for (int k = c + 1; k < 6; k++) w -= F[k][c] * xx[k];
                 xx[c] = w * dinv[c];
             }
+            if (p == 0) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) { v[j0 + c] = xx[c]; s_y[c] = xx[c]; }
+                for (int c = 0; c < 6; c++) { v[j0 + c] = xx[c]; s_y[c] = xx[c]; }
+            }
         }
         __syncthreads();
         if (have && I == J && K < J) {
@@ -1785,8 +1822,9 @@ __global__ __launch_bounds__(DS_TPB) void k_dense_small_solve(const double* __re
             for (int c = 0; c < 6; c++) {
                 double w = 0;
 #pragma unroll
-                for (int r = 0; r < 6; r++) w += T[r][c] * s_y[r];
-                v[6 * K + c] -= w;
+                for (int rr = 0; rr < 3; rr++) w += T[rr][c] * s_y[3 * p + rr];
+                w += __shfl_xor(w, 1, 64);                                   // the tile's other three rows
+                if (p == 0) v[6 * K + c] -= w;
             }
         }
         __syncthreads();

@@ -29,6 +29,7 @@ void ba_launch_pose_rt(hipStream_t, const BaDev&);
 int ba_errors_blocks(const BaDev&);
 void ba_launch_errors(hipStream_t, const BaDev&, double hd, double* partial, double* out);
 void ba_launch_linearize(hipStream_t, const BaDev&, double hd, double lambda, bool keep_hpl, bool landmarks_only);
+void ba_launch_lin_pose(hipStream_t, const BaDev&, double hd);
 int comm_allreduce_u8_max(ccm_ctx* c, uint8_t* dev, size_t n);
 // ba_sparse.hip
 size_t sp_scan_temp_bytes(size_t n);
@@ -98,10 +99,11 @@ struct BaState {
     hipEvent_t ev_inv = nullptr;           // the side stream has finished an inversion
     hipEvent_t ev_up = nullptr;            // the side stream has finished uploading observations, information values and points
     hipEvent_t ev_copy = nullptr;          // the main stream has copied the last inverse out of the side stream's work matrix
+    hipEvent_t ev_chi = nullptr;           // a trial's chi2 has reached the host (the stream goes on with the next iteration's pose-side linearisation)
     std::vector<hipEvent_t> clock_ev;      // phase timers of large problems (events instead of stream synchronisations)
     double* pinned = nullptr;          // 16 doubles of page-locked host memory for small device->host reads
     DevBuf poses, Rt, intr, free_of, pose_of_free, points, edge_pose, edge_point, obs, info, active, err,
-           pt_first, pose_first, pose_edges, Hpp, bp, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
+           pt_first, pose_first, pose_edges, Hpp, bp, Hpp2, bp2, Hll, bl, Hpl, Dinv, Hs, bs, x, save_poses, save_points,
            partial, scal, flags, info_dev, tmp_ll, pp_diag, gather,
            sp_cnt, sp_off, sp_key, sp_val, sp_key2, sp_val2, sp_map, sp_id, sp_tmp, blk_row, blk_col, diag_id, seg_start, seg_end,
            ent_key, ent_val, ent_key2, ent_val2, row_ptr, Hb, Y, db, Minv, pcg_w, pcg_pap, pcg_part, pcg_sc, pcg_aci, pcg_coarse, pcg_acw, pcg_svec, pcg_hf, pcg_ecol, pcg_ca, pcg_aggmap, pcg_pairs, ce;
@@ -114,10 +116,11 @@ void ba_state_free(BaState* s)
     if (s->ev_inv) (void)hipEventDestroy(s->ev_inv);
     if (s->ev_up) (void)hipEventDestroy(s->ev_up);
     if (s->ev_copy) (void)hipEventDestroy(s->ev_copy);
+    if (s->ev_chi) (void)hipEventDestroy(s->ev_chi);
     for (hipEvent_t e : s->clock_ev) (void)hipEventDestroy(e);
     if (s->pinned) (void)hipHostFree(s->pinned);
     DevBuf* all[] = { &s->poses, &s->Rt, &s->intr, &s->free_of, &s->pose_of_free, &s->points, &s->edge_pose, &s->edge_point,
-                      &s->obs, &s->info, &s->active, &s->err, &s->pt_first, &s->pose_first, &s->pose_edges, &s->Hpp, &s->bp,
+                      &s->obs, &s->info, &s->active, &s->err, &s->pt_first, &s->pose_first, &s->pose_edges, &s->Hpp, &s->bp, &s->Hpp2, &s->bp2,
                       &s->Hll, &s->bl, &s->Hpl, &s->Dinv, &s->Hs, &s->bs, &s->x, &s->save_poses, &s->save_points,
                       &s->partial, &s->scal, &s->flags, &s->info_dev, &s->tmp_ll, &s->pp_diag, &s->gather,
                       &s->sp_cnt, &s->sp_off, &s->sp_key, &s->sp_val, &s->sp_key2, &s->sp_val2, &s->sp_map, &s->sp_id, &s->sp_tmp, &s->blk_row,
@@ -447,6 +450,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
     CCM_RESERVE(c, S.active, std::max<size_t>(E, 16)); CCM_RESERVE(c, S.flags, std::max<size_t>(E, 16));
     CCM_RESERVE(c, S.err, std::max<size_t>(2 * (size_t)E * 8, 16));
     CCM_RESERVE(c, S.Hpp, std::max<size_t>(36 * (size_t)nfree * 8, 16)); CCM_RESERVE(c, S.bp, std::max<size_t>((size_t)n * 8, 16));
+    CCM_RESERVE(c, S.Hpp2, std::max<size_t>(36 * (size_t)nfree * 8, 16)); CCM_RESERVE(c, S.bp2, std::max<size_t>((size_t)n * 8, 16));   // the LM loop's look-ahead (below)
     CCM_RESERVE(c, S.Hll, std::max<size_t>(9 * (size_t)L * 8, 16)); CCM_RESERVE(c, S.bl, std::max<size_t>(3 * (size_t)L * 8, 16));
     CCM_RESERVE(c, S.Hpl, std::max<size_t>(18 * (size_t)E * 8, 16)); CCM_RESERVE(c, S.Dinv, std::max<size_t>(9 * (size_t)L * 8, 16));
     CCM_RESERVE(c, S.x, std::max<size_t>(nxl * 8, 16));
@@ -680,7 +684,16 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         return CCM_OK;
     };
     // chi2 (+ optionally scale) of the current state, summed over ranks
-    auto eval_chi2 = [&](double hd, bool with_scale, double lambda, double* chi, double* scale, bool rt_current = false) -> int {
+    // Look-ahead of the LM loop (one rank): a trial is nearly always accepted, and the keyframes' side of the next linearisation (Hpp, bp)
+    // depends on nothing but the state the trial has just produced -- so it is enqueued right behind the trial's chi2, into a second pair
+    // of buffers, and runs while the host waits for the chi2 (an event, not the stream), decides and launches the landmark side.  An accepted
+    // trial's iteration swaps the buffers in and launches the landmarks alone; a rejected one never looks at them.  Same kernel on the same
+    // state: the values are those the iteration would have computed itself.
+    double* Hpp_alt = S.Hpp2.as<double>();
+    double* bp_alt = S.bp2.as<double>();
+    static const bool no_ahead = getenv("CCM_BA_NO_LOOKAHEAD") && atoi(getenv("CCM_BA_NO_LOOKAHEAD")) != 0;                  // test / A-B switch
+    if (!S.ev_chi) CCM_HIP(c, hipEventCreateWithFlags(&S.ev_chi, hipEventDisableTiming));
+    auto eval_chi2 = [&](double hd, bool with_scale, double lambda, double* chi, double* scale, bool rt_current = false, bool look_ahead = false) -> int {
         if (!rt_current) ba_launch_pose_rt(st, D);                             // (k_ba_update leaves the matrices of the poses it moved)
         if (with_scale) ba_launch_errors_scale(st, D, hd, lambda, rank == 0 ? 1 : 0, partial, scal);
         else if (E > 0) ba_launch_errors(st, D, hd, partial, scal);
@@ -696,7 +709,13 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
             stop_collective = S.pinned[10] > 0.0;
         } else {
             CCM_HIP(c, hipMemcpyAsync(S.pinned + 8, scal, with_scale ? 16 : 8, hipMemcpyDeviceToHost, st));
-            CCM_HIP(c, hipStreamSynchronize(st));
+            if (look_ahead) {
+                CCM_HIP(c, hipEventRecord(S.ev_chi, st));
+                BaDev D2 = D;
+                D2.Hpp = Hpp_alt; D2.bp = bp_alt;
+                { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_lin_pose(st, D2, hd); }
+                CCM_HIP(c, hipEventSynchronize(S.ev_chi));             // (polling the event or the page-locked slots instead measured the same)
+            } else CCM_HIP(c, hipStreamSynchronize(st));
         }
         *chi = S.pinned[8]; if (scale) *scale = S.pinned[9];
         return CCM_OK;
@@ -735,6 +754,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
         // rides on this evaluation's all-reduce) the evaluation runs as before.
         bool chi_carried = false;
         double carried_chi = 0;
+        bool ahead_ready = false;                            // Hpp_alt / bp_alt hold the pose side of the current state
         for (int it = 0; it < iterations; it++) {
             if (stop_requested()) { res->stopped = 1; break; }                    // !terminate(), sparse_optimizer.cpp:376
             auto t0 = clk::now();
@@ -750,7 +770,10 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
             const bool fused_schur = it > 0 && nfree > 0 && lambda > 0;
             // (and without Hpl, which only a repeated trial reads: see k_ba_lin_landmark MODE 2)
             static const bool keep_hpl = getenv("CCM_BA_KEEP_HPL") && atoi(getenv("CCM_BA_KEEP_HPL")) != 0;          // test / A-B switch
-            { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_linearize(st, D, huber, fused_schur ? lambda : 0.0, keep_hpl, false); }
+            const bool use_ahead = ahead_ready;
+            ahead_ready = false;
+            if (use_ahead) { std::swap(D.Hpp, Hpp_alt); std::swap(D.bp, bp_alt); }
+            { ProfScope ps(c, CCM_PROF_BA_LINEARIZE); ba_launch_linearize(st, D, huber, fused_schur ? lambda : 0.0, keep_hpl, use_ahead); }
             bool landmark_share_ready = fused_schur;
             bool hpl_valid = !fused_schur || keep_hpl;
             if (it == 0) {                                                          // computeLambdaInit
@@ -776,7 +799,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                 RoctxRange trial_("ba:trial (schur + solve + update)");
                 // (push: k_ba_update saves the state it is about to change; the fixed keyframes' poses were copied once, above)
                 int ok2 = 1;
-                bool updated = false;
+                bool updated = false, looked_ahead = false;
                 // The dense solve's verdict ("not positive definite") of a small, single-rank problem is read together with the
                 // trial's chi2 instead of in a round trip of its own (a local BA is launch- and round-trip-bound: three host syncs
                 // per trial were a fifth of the call): the trial's update is applied as if the solve had succeeded and, if it had
@@ -977,7 +1000,8 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                     if (L > 0) { ProfScope ps(c, CCM_PROF_BA_BACKSUB); ba_launch_backsub(st, D, lambda); }
                     ba_launch_update(st, D, S.save_poses.as<double>(), S.save_points.as<double>());
                     updated = true;
-                    if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale, true))) return rc;     // synchronises the stream
+                    looked_ahead = ranks == 1 && nfree > 0 && !no_ahead && it + 1 < iterations;
+                    if ((rc = eval_chi2(huber, true, lambda, &tempChi, &scale, true, looked_ahead))) return rc;     // synchronises the stream (or, looking ahead, waits for the chi2 alone)
                     if (dense_info_pending && *dense_info != 0) { ok2 = 0; tempChi = DBL_MAX; scale = 0; }
                 }
                 scale += 1e-3;
@@ -991,6 +1015,7 @@ static int ba_solve_impl(ccm_ctx* c, ccm_ba_problem* pb, const ccm_ba_options* o
                     alpha = std::min(alpha, 2. / 3.);
                     lambda *= std::max(1. / 3., alpha);
                     ni = 2; currentChi = tempChi;                                   // discardTop
+                    ahead_ready = looked_ahead;
                 } else {
                     lambda *= ni; ni *= 2;
                     if (updated) {                                                  // pop (a trial whose solve failed has not moved anything)

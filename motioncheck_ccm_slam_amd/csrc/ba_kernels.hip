@@ -455,6 +455,7 @@ void ba_launch_errors(hipStream_t s, const BaDev& D, double hd, double* partial,
 #endif
 // lambda > 0: the landmarks' share of the Schur step for that lambda is computed along (MODE 1, or MODE 2 when the caller can do
 // without Hpl); landmarks_only: the rebuild of Hpl after a rejected trial of a MODE 2 iteration
+void ba_launch_lin_pose(hipStream_t s, const BaDev& D, double hd);
 void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd, double lambda, bool keep_hpl, bool landmarks_only)
 {
     const dim3 grid(nblk((long long)BA_LM_LANES * D.L, 256));                                       // a zero-size grid is a launch error
@@ -462,6 +463,11 @@ void ba_launch_linearize(hipStream_t s, const BaDev& D, double hd, double lambda
     else if (D.L > 0 && lambda > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, 2>), grid, dim3(256), 0, s, D, hd, lambda);
     else if (D.L > 0) hipLaunchKernelGGL((k_ba_lin_landmark<BA_LM_LANES, 0>), grid, dim3(256), 0, s, D, hd, 0.0);
     if (landmarks_only) return;
+    ba_launch_lin_pose(s, D, hd);
+}
+// the keyframes' side alone: Hpp, bp of the state as it is (also launched ahead of time by the LM loop: ba_host.cpp)
+void ba_launch_lin_pose(hipStream_t s, const BaDev& D, double hd)
+{
     // few keyframes with long edge lists (local BA): a workgroup per keyframe; maps with thousands of keyframes: a wave each (measured:
     // the workgroup form costs config 5 another 60 us per linearisation, the wave form costs config 4 40 us)
     // (16 waves per keyframe measured no faster than 4 at 20 keyframes x 1300 edges: 22.1 against 21.1 us -- the keyframe's edges are

@@ -386,6 +386,9 @@ def main():
                                  "gather_GBps": round(r["schur_pairs"] * 288.0 / (ms_s / n_s * 1e-3) / 1e9, 1),
                                  "gather_note": "pairs x 2 operand blocks x 144 B: what the GEMM's operands amount to if nothing is reused"}
             ms_l, n_l = pr["ba_linearize"]
+            # (per LM iteration: the library brackets the landmark side and the keyframes' side separately when the latter is enqueued
+            #  ahead of the LM decision, so the number of brackets is not the number of linearisations)
+            n_l = rp["iterations_done"] if n_l else 0
             if n_l:
                 gb = BA_BYTES_PER_EDGE * E / world / (ms_l / n_l * 1e-3) / 1e9
                 roof["linearize"] = {"kernels": "k_ba_lin_landmark + k_ba_lin_pose", "bound": "hbm", "ms_per_iteration": round(ms_l / n_l, 4),

@@ -1178,7 +1178,13 @@ __global__ __launch_bounds__(256) void k_ppcg_init(const double* __restrict__ b,
 // thread is requested before the first is used -- the rows of Aci (they do not depend on P^T in), the columns of the cluster
 // inverses and the CA rows -- so the whole preconditioner costs about two L2 round trips plus the time 0.5 MB take through one CU's
 // path to L2.  Partial sums meet in LDS and are added in a fixed order.
-#define PCG_PSLOTS (PCG_UPD_KF / (PCG_CL * PCG_AGG) + 2)       // aggregates a block of PCG_UPD_KF keyframes can touch
+#ifndef PP_KF
+#define PP_KF 8                                                // keyframes per workgroup of k_ppcg_prec: one cluster.  Measured at config 5 (solve phase of optimize(20),
+                                                               // same-box A/B): 32 keyframes (63 workgroups, 28 rows of the inverse each) 17.72 ms, 16: 17.72, 8 (250, 14 rows): 17.35
+#endif
+#define PP_UTPB (6 * PP_KF)
+#define PCG_PSLOTS (PP_KF / (PCG_CL * PCG_AGG) + 2)            // aggregates a block of PP_KF keyframes can touch
+static_assert(PP_UTPB % PCG_CN == 0, "a block must hold whole clusters");
 #define PP_TPB 1024
 #define PP_NW (PP_TPB / 64)
 #define PP_CQ 4                                                // a column of CA is summed by PP_CQ threads (a quarter of the support rows each)
@@ -1186,16 +1192,16 @@ __global__ __launch_bounds__(256) void k_ppcg_init(const double* __restrict__ b,
 #define PP_COLS 4                                              // columns of CA per thread: PP_COLS * (PP_TPB / PP_CQ) >= coarse pitch
 #define PP_D2 8                                                // 16-byte pieces of an Aci row per lane: 128 * PP_D2 >= coarse pitch
 #define PP_ROWS_PER_WAVE ((PCG_PSLOTS * PCG_CDOF + PP_NW - 1) / PP_NW)
-static_assert(PCG_CN % PP_MQ == 0 && PP_MQ * PCG_UPD_TPB <= PP_TPB, "cluster product split");
+static_assert(PCG_CN % PP_MQ == 0 && PP_MQ * PP_UTPB <= PP_TPB, "cluster product split");
 __host__ __device__ inline bool ppcg_prec_fits(int ncp, int agg_keyframes)
-{ return ncp <= PP_COLS * (PP_TPB / PP_CQ) && ncp <= 128 * PP_D2 && (2 * agg_keyframes) % PP_CQ == 0 && PCG_UPD_KF / agg_keyframes + 2 <= PCG_PSLOTS; }
+{ return ncp <= PP_COLS * (PP_TPB / PP_CQ) && ncp <= 128 * PP_D2 && (2 * agg_keyframes) % PP_CQ == 0 && PP_KF / agg_keyframes + 2 <= PCG_PSLOTS; }
 __global__ __launch_bounds__(PP_TPB) void k_ppcg_prec(const double* __restrict__ Minv, int nfree, double* __restrict__ wb, int in_slot, int out_slot,
                                                       const double* __restrict__ Aci, int nc, int ncp, const double* __restrict__ CA, int nagg,
                                                       const double* __restrict__ svec, const double* __restrict__ cen,
                                                       const double* __restrict__ part, double* __restrict__ sc, int do_scalars)
 {
     const long long n = 6LL * nfree;
-    const int nb32 = (nfree + PCG_UPD_KF - 1) / PCG_UPD_KF;
+    const int nb32 = (nfree + PP_KF - 1) / PP_KF;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x == nb32) {
         if (!do_scalars) return;
@@ -1222,10 +1228,10 @@ __global__ __launch_bounds__(PP_TPB) void k_ppcg_prec(const double* __restrict__
         return;
     }
     extern __shared__ double pp_lds[];                     // rc[ncp] (P^T in), cpart[PP_CQ][ncp]
-    __shared__ double ws[PCG_UPD_TPB], mpart[PP_MQ][PCG_UPD_TPB], yl[PCG_PSLOTS * PCG_CDOF];
+    __shared__ double ws[PP_UTPB], mpart[PP_MQ][PP_UTPB], yl[PCG_PSLOTS * PCG_CDOF];
     double* rc = pp_lds;
     double* cpart = pp_lds + ncp;
-    const int f0 = blockIdx.x * PCG_UPD_KF;
+    const int f0 = blockIdx.x * PP_KF;
     const int A = PCG_CL * pcg_agg_clusters(nfree);
     typedef double pp_d2 __attribute__((ext_vector_type(2)));
     // ---- every load of this thread, requested back to back
@@ -1244,7 +1250,7 @@ __global__ __launch_bounds__(PP_TPB) void k_ppcg_prec(const double* __restrict__
         }
     }
     // (2) cluster inverse: thread (unknown u, quarter mq) takes PCG_CN / PP_MQ terms of the unknown's column
-    const int mu = threadIdx.x % PCG_UPD_TPB, mq = threadIdx.x / PCG_UPD_TPB;
+    const int mu = threadIdx.x % PP_UTPB, mq = threadIdx.x / PP_UTPB;
     const long long mo = (long long)f0 * 6 + mu;
     const bool mlive = mq < PP_MQ && mo < n;
     double mv[PCG_CN / PP_MQ];
@@ -1254,7 +1260,7 @@ __global__ __launch_bounds__(PP_TPB) void k_ppcg_prec(const double* __restrict__
 #pragma unroll
         for (int k = 0; k < PCG_CN / PP_MQ; k++) mv[k] = M[k * PCG_CN];          // symmetric: column li read with unit stride across lanes
     }
-    if (threadIdx.x < PCG_UPD_TPB) ws[threadIdx.x] = mo < n ? wb[(long long)in_slot * n + mo] : 0.0;
+    if (threadIdx.x < PP_UTPB) ws[threadIdx.x] = mo < n ? wb[(long long)in_slot * n + mo] : 0.0;
     // (3) P^T in: thread (column group, quarter cq) sums its quarter of the 2 A support rows of up to PP_COLS columns
     if (Aci) {
         const int cq = threadIdx.x / (PP_TPB / PP_CQ), cj = threadIdx.x % (PP_TPB / PP_CQ);
@@ -1297,7 +1303,7 @@ __global__ __launch_bounds__(PP_TPB) void k_ppcg_prec(const double* __restrict__
         }
         __syncthreads();
     }
-    if (threadIdx.x < PCG_UPD_TPB && mo < n) {
+    if (threadIdx.x < PP_UTPB && mo < n) {
         double z = ((mpart[0][mu] + mpart[1][mu]) + mpart[2][mu]) + mpart[3][mu];
         if (Aci) {
             const int f = (int)(mo / 6), d = (int)(mo - 6LL * f);
@@ -1585,7 +1591,7 @@ void ppcg_launch_expand(hipStream_t s, const double* Hb, const unsigned* ekey, c
 static void ppcg_launch_prec(hipStream_t s, const double* Minv, int nfree, double* wb, int in_slot, int out_slot, const PcgCoarse& C, const PpcgBufs& B,
                              double* part, double* sc, int do_scalars)
 {
-    const int nb32 = nblk(nfree, PCG_UPD_KF);
+    const int nb32 = nblk(nfree, PP_KF);
     const int nagg = C.Aci ? pcg_coarse_aggregates(nfree) : 0, nc = PCG_CDOF * nagg, ncp = C.Aci ? pcg_coarse_pitch(nfree) : 0;
     const size_t lds = (size_t)((1 + PP_CQ) * ncp + 2) * sizeof(double);
     hipLaunchKernelGGL(k_ppcg_prec, dim3(nb32 + 1), dim3(PP_TPB), lds, s, Minv, nfree, wb, in_slot, out_slot, (const double*)C.Aci, nc, ncp, (const double*)(C.Aci ? B.CA : nullptr), nagg,
